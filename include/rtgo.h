@@ -1,0 +1,203 @@
+/*
+ * rtgo.h — C-ABI of librtgo_hip.so, the MI355X (gfx950) render backend for the
+ * raytracer-go hot path:  camera ray-gen -> octree traversal + ray/sphere +
+ * ray/triangle -> material shading -> Monte-Carlo shadow rays -> pixel
+ * accumulate -> RGBA8.
+ *
+ * The reference (btleedev/raytracer-go) has no FFI seam: its boundary is the Go
+ * package API `raytracer.GenerateImage(ImageSpec, Scene) *image.RGBA`
+ * (raytracer/raytracer.go:58).  The entry points below are what a cgo shim
+ * inside GenerateImage binds (see INTEGRATION.md for that shim).  Everything is
+ * plain C: POD structs, caller-owned pointers + sizes, int status returns.
+ *
+ * Conventions
+ *   - Scene inputs are float64, exactly as Go's r3.Vec{X,Y,Z float64}; the
+ *     library narrows to fp32 at upload (the device path computes in fp32).
+ *   - All input pointers are borrowed for the duration of the call only.
+ *   - Return 0 = RT_OK; negative = error, text via rt_last_error() (thread-local).
+ *   - Shape index (position in rt_scene_desc.shapes) is the primitive ID that
+ *     rt_trace_rays reports — same order as Scene.Shapes (raytracer.go:44).
+ */
+#ifndef RTGO_H
+#define RTGO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)   /* bad argument / malformed scene                       */
+#define RT_ERR_DEVICE (-2)    /* HIP runtime error or no gfx950 device                */
+#define RT_ERR_ALGORITHM (-3) /* unknown BvhTraversalAlgorithm: the reference panics, */
+                              /* accelerationstructures.go:73                         */
+#define RT_ERR_LIMIT (-4)     /* scene exceeds a documented capacity limit            */
+
+typedef struct rt_vec3 { double x, y, z; } rt_vec3; /* r3.Vec */
+
+/* ---- textures: texture.go:16-25 ------------------------------------------ */
+enum { RT_TEX_CHECKERS = 1, RT_TEX_IMAGE = 2 };
+typedef struct rt_texture {
+    int32_t kind;            /* RT_TEX_*                                               */
+    int32_t width, height;   /* image: Img.Bounds().Size()                             */
+    rt_vec3 color1, color2;  /* checkers: ColorFrac1/2                                 */
+    double checkers_width, checkers_height;
+    const uint8_t* rgba;     /* image: Img.Pix, row-major RGBA8, width*height*4 bytes  */
+} rt_texture;
+
+/* ---- materials: material.go:13-32 ---------------------------------------- */
+enum { RT_MAT_STANDARD = 1, RT_MAT_METAL = 2, RT_MAT_DIELECTRIC = 3, RT_MAT_PHONGBLINN = 4 };
+typedef struct rt_material {
+    int32_t kind;            /* RT_MAT_*                                               */
+    int32_t texture;         /* index into textures, -1 = nil (Standard / PhongBlinn)  */
+    rt_vec3 color;           /* Standard.ColorFrac / Metal.Albedo / PhongBlinn.ColorFrac */
+    rt_vec3 specular_color;  /* PhongBlinn.SpecularColorFrac                           */
+    double param;            /* Metal.Fuzz / Dielectric.RefractiveIndex / PhongBlinn.SpecHardness */
+} rt_material;
+
+/* ---- shapes: shape.go:33-45 ---------------------------------------------- */
+enum { RT_SHAPE_SPHERE = 1, RT_SHAPE_TRIANGLE = 2 };
+typedef struct rt_shape {
+    int32_t kind;            /* RT_SHAPE_*                                             */
+    int32_t material;        /* index into materials                                   */
+    int32_t single_sided;    /* TrianglePlane.SingleSided                              */
+    int32_t _pad;
+    rt_vec3 a;               /* Sphere.Center      / TrianglePlane.PointA              */
+    rt_vec3 b;               /* {Radius,0,0}       / TrianglePlane.PointB              */
+    rt_vec3 c;               /* unused             / TrianglePlane.PointC              */
+} rt_shape;
+
+/* ---- lights: light.go:18-39 ---------------------------------------------- */
+enum { RT_LIGHT_AMBIENT = 1, RT_LIGHT_POINT = 2, RT_LIGHT_SPOT = 3 };
+typedef struct rt_light {
+    int32_t kind;            /* RT_LIGHT_*                                             */
+    int32_t _pad;
+    rt_vec3 color;           /* ColorFrac                                              */
+    rt_vec3 position;        /* Point/Spot                                             */
+    rt_vec3 look_at;         /* Spot                                                   */
+    double intensity;        /* LightIntensity                                         */
+    double specular_intensity;
+    double angle_deg;        /* Spot.Angle, half-angle in degrees                      */
+    double decay;            /* InverseSquareLawDecayFactor                            */
+} rt_light;
+
+/* ---- Scene (raytracer.go:35-46); CameraFocusPoint is dead in the reference -- */
+typedef struct rt_scene_desc {
+    rt_vec3 camera_look_from, camera_look_at, camera_up;
+    double camera_aperture;  /* CameraAperature                                        */
+    double camera_fov_deg;   /* CameraFov                                              */
+    const rt_shape* shapes;       int64_t n_shapes;
+    const rt_material* materials; int64_t n_materials;
+    const rt_texture* textures;   int64_t n_textures;
+    const rt_light* lights;       int64_t n_lights;
+} rt_scene_desc;
+
+/* ---- ImageSpec (raytracer.go:25-33) --------------------------------------- */
+enum { RT_BVH_DIJKSTRA = 0, RT_BVH_DEPTH_FIRST_SEARCH = 1 }; /* raytracer.go:20-23 */
+typedef struct rt_image_spec {
+    int32_t width, height;
+    int32_t anti_aliasing_factor;
+    int32_t ray_tracing_max_depth;
+    int32_t soft_shadow_monte_carlo_repetitions;
+    int32_t worker_count;             /* accepted, ignored (goroutine count)           */
+    int32_t bvh_traversal_algorithm;  /* 0|1 accepted (both map to the device stack    */
+                                      /* traversal); anything else = RT_ERR_ALGORITHM  */
+    int32_t _pad;
+} rt_image_spec;
+
+/* ---- knobs the Go API has no field for ------------------------------------ */
+enum { RT_PART_ALL = 0, RT_PART_TILES = 1, RT_PART_SAMPLES = 2 };
+typedef struct rt_partition {
+    uint64_t seed;            /* Philox key; the reference uses the unseeded global math/rand */
+    int32_t mode;             /* RT_PART_*                                             */
+    int32_t rank, world_size; /* this call renders rank's share of tiles / samples     */
+    int32_t tile_size;        /* RT_PART_TILES: square tile edge in pixels (0 = 64)    */
+    int64_t max_paths_per_batch; /* 0 = library default                               */
+} rt_partition;
+
+typedef struct rt_stats {
+    uint64_t rays_primary;       /* closest-hit traversals at bounce 0                 */
+    uint64_t rays_continuation;  /* closest-hit traversals at bounce > 0               */
+    uint64_t rays_shadow;        /* any-hit traversals actually launched               */
+    uint64_t rays_shadow_reference_equivalent; /* incl. the ones the reference traces
+                                    before its spot-cone test, light.go:124            */
+    uint64_t phong_hits;
+    uint64_t paths;              /* (pixel, sample) pairs rendered by this call        */
+    double ms_build;             /* host octree build + flatten + upload (scene create)*/
+    double ms_render;            /* device time of the render call (hipEvent)          */
+    double ms_extend, ms_shadow, ms_shade; /* per-stage device time, if timed          */
+} rt_stats;
+
+typedef struct rt_scene_info {
+    int64_t n_shapes, n_inner_nodes, n_child_records;
+    int32_t tree_depth;          /* after single-child chain collapse                  */
+    int32_t stack_bound;         /* worst-case traversal stack entries                 */
+    int64_t device_bytes;
+} rt_scene_info;
+
+typedef struct rt_scene rt_scene; /* opaque: flattened octree + tables resident in HBM */
+
+/* Thread-local text of the last error.  The Go shim turns it into a panic, matching
+ * the reference's error behaviour (accelerationstructures.go:73, example.go:36-44). */
+const char* rt_last_error(void);
+
+/* Library / device probe.  Fails (RT_ERR_DEVICE) when no HIP device is visible. */
+int rt_init(int device);
+
+/* Replaces NewBoundingVolumeHierarchy(&scene.Shapes) (accelerationstructures.go:27-65,
+ * called at raytracer.go:69) + NewCamera (camera.go:18-35, raytracer.go:59-68):
+ * builds the octree on the host, flattens it to child-record / primitive arrays and
+ * uploads scene, materials, textures and lights to `device`. */
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);
+
+/* Replaces the body of GenerateImage after the BVH build (raytracer.go:70-106): the
+ * computePixel workers (raytracer.go:109-133), color() (raytracer.go:135-162) and the
+ * RGBA8 quantisation (raytracer.go:93-96).  rgba_out: caller-allocated host buffer,
+ * width*height*4 bytes, row 0 = top (raytracer.go:125).  stats may be NULL. */
+int rt_render(rt_scene* scene, const rt_image_spec* spec, const rt_partition* part,
+              uint8_t* rgba_out, rt_stats* stats);
+
+/* Same path, but stops before the divide/quantise: un-normalised fp32 RGB sums
+ * (width*height*3 floats, row 0 = top) of this rank's share are ADDED into
+ * d_accum_rgb, a DEVICE pointer owned by the caller (e.g. a torch tensor that is then
+ * reduced over RCCL).  hip_stream: hipStream_t to enqueue on (NULL = default stream).
+ * The call returns after the work has been enqueued and the stats have been read back
+ * (it synchronises the stream only when stats != NULL). */
+int rt_render_accum_device(rt_scene* scene, const rt_image_spec* spec, const rt_partition* part,
+                           float* d_accum_rgb, void* hip_stream, rt_stats* stats);
+
+/* Host-buffer convenience over rt_render_accum_device (used for RMSE checks). */
+int rt_render_accum(rt_scene* scene, const rt_image_spec* spec, const rt_partition* part,
+                    float* accum_rgb_out, rt_stats* stats);
+
+/* raytracer.go:93-96 + :119 on device: c = sum/spp; uint8(min(255, c*255.99)); A=255.
+ * d_accum_rgb: device, width*height*3 floats.  d_rgba_out: device, width*height*4. */
+int rt_resolve_device(const float* d_accum_rgb, int32_t width, int32_t height, int32_t spp,
+                      uint8_t* d_rgba_out, void* hip_stream);
+
+/* One-shot GenerateImage(imageSpec, scene): scene create + render + destroy. */
+int rt_generate_image(const rt_scene_desc* desc, const rt_image_spec* spec,
+                      const rt_partition* part, uint8_t* rgba_out, rt_stats* stats);
+
+/* Parity entry point: nearest hit of explicit rays, as bvh.trace(r, tMin)
+ * (accelerationstructures.go:81-124).  rays: n * 8 floats {ox,oy,oz, dx,dy,dz, tMin, 0};
+ * prim_out[n]: shape index or -1; t_out[n]: hit t (undefined on miss).
+ * any_hit != 0 runs the shadow-ray traversal instead (light.go:141-160 semantics with
+ * ray slot 7 = tMax): prim_out = 1 if occluded else 0. */
+int rt_trace_rays(rt_scene* scene, const float* rays, int64_t n, int32_t any_hit,
+                  int32_t* prim_out, float* t_out);
+
+/* Camera rays exactly as the device generates them (camera.go:37-44 + raytracer.go:114-116)
+ * for parity tests: for sample s of pixel (i, j) — j counted from the bottom as in the
+ * reference — writes {ox,oy,oz,dx,dy,dz} * n.  pixels: n * 3 int32 {i, j, s}. */
+int rt_camera_rays(rt_scene* scene, const rt_image_spec* spec, uint64_t seed,
+                   const int32_t* pixels, int64_t n, float* rays_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTGO_H */

@@ -1,0 +1,136 @@
+"""ctypes bridge to the CPU oracle (oracle/librtgo_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg — never by the product package.
+"""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "librtgo_oracle.so")
+
+F64_DIJKSTRA, F64_DFS, F32_STACK = 0, 1, 2
+
+_pkg = importlib.import_module("raytracer-go_amd")
+_abi = _pkg._abi
+
+
+class OrcCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "rays_primary", "rays_continuation", "rays_shadow", "phong_hits",
+        "inner_primary", "leaf_primary", "inner_continuation", "leaf_continuation",
+        "inner_shadow", "leaf_shadow")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def build(force=False):
+    """Compile the oracle with g++ (no GPU needed)."""
+    src = os.path.join(_HERE, "rtgo_oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_scene_create.restype = C.c_void_p
+        L.orc_scene_create.argtypes = [C.c_void_p]
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_tree_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_trace_rays.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+        L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_scatter_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
+                                        C.c_uint32, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def default_threads():
+    return max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "64"))))
+
+
+class OracleScene:
+    def __init__(self, scene):
+        self._flat = _abi.FlatScene(scene)
+        self._h = lib().orc_scene_create(C.addressof(self._flat.desc))
+        if not self._h:
+            raise RuntimeError(lib().orc_last_error().decode())
+
+    def close(self):
+        if self._h:
+            lib().orc_scene_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+    def tree_info(self):
+        out = np.zeros(4, dtype=np.int64)
+        lib().orc_tree_info(self._h, out.ctypes.data)
+        return {"pointer_nodes": int(out[0]), "inner": int(out[1]), "max_depth": int(out[2]), "leaves": int(out[3])}
+
+    def trace_rays(self, rays, mode=F64_DIJKSTRA, any_hit=False, threads=None, counters=False):
+        """rays: (n, 8) {o, d, tMin, tMax}.  Returns (prim, t[, n_inner, n_leaf])."""
+        rays = np.ascontiguousarray(rays, dtype=np.float64)
+        n = rays.shape[0]
+        prim = np.empty(n, dtype=np.int32)
+        t = np.empty(n, dtype=np.float64)
+        ni = np.zeros(n, dtype=np.uint32)
+        nl = np.zeros(n, dtype=np.uint32)
+        rc = lib().orc_trace_rays(self._h, mode, rays.ctypes.data, n, 1 if any_hit else 0, prim.ctypes.data,
+                                  t.ctypes.data, ni.ctypes.data, nl.ctypes.data, threads or default_threads())
+        if rc != 0:
+            raise RuntimeError(lib().orc_last_error().decode())
+        return (prim, t, ni, nl) if counters else (prim, t)
+
+    def camera_rays(self, spec, pixels, seed=0x5EED, mode=F64_DIJKSTRA):
+        s = _abi.image_spec(spec)
+        pixels = np.ascontiguousarray(pixels, dtype=np.int32)
+        out = np.empty((pixels.shape[0], 6), dtype=np.float64)
+        lib().orc_camera_rays(self._h, C.addressof(s), seed, mode, pixels.ctypes.data, pixels.shape[0], out.ctypes.data)
+        return out
+
+    def render(self, spec, seed=0x5EED, mode=F64_DIJKSTRA, threads=None, rows=None, samples=None, rgba=True):
+        """Returns (accum HxWx3 float64 un-normalised sums, rgba HxWx4 uint8 or None, counters dict)."""
+        s = _abi.image_spec(spec)
+        H, W = spec.Height, spec.Width
+        row0, row1 = rows if rows else (0, H)
+        s0, s1 = samples if samples else (0, spec.AntiAliasingFactor)
+        accum = np.zeros((H, W, 3), dtype=np.float64)
+        pix = np.zeros((H, W, 4), dtype=np.uint8) if rgba else None
+        ctr = OrcCounters()
+        rc = lib().orc_render(self._h, C.addressof(s), seed, mode, threads or default_threads(), row0, row1, s0, s1,
+                              accum.ctypes.data, pix.ctypes.data if rgba else None, C.addressof(ctr))
+        if rc != 0:
+            raise RuntimeError(lib().orc_last_error().decode())
+        return accum, pix, ctr.as_dict()
+
+    def scatter_probe(self, spec, ray6, pixel=0, sample=0, bounce=0, seed=0x5EED):
+        s = _abi.image_spec(spec)
+        ray6 = np.ascontiguousarray(ray6, dtype=np.float64)
+        out = np.zeros(20, dtype=np.float64)
+        rc = lib().orc_scatter_probe(self._h, C.addressof(s), seed, ray6.ctypes.data, pixel, sample, bounce, out.ctypes.data)
+        return rc, out
