@@ -554,21 +554,24 @@ bool trace_stack_f32(const Scene& sc, const Ray<float>& r, float tmin, float tma
     for (;;) {
         if (tc) tc->inner++;
         Node* pending[8]; int np = 0;
+        Node* leaves[8]; int nl = 0;
+        // pass 1: every present child's box against the best t at node entry, in ray order
+        const float entry_best = hr.t;
         for (int k = 0; k < 8; ++k) {
             Node* c = cur->children[k ^ sr.sign];
             if (!c) continue;
             // box of the slot is the box of the un-collapsed child (identical after refit)
             Node* e = effective(c);
-            if (!slab_f32(sr, e->fmin, e->fmax, t0, hr.t)) continue;
-            if (e->leaf) {
-                if (tc) tc->leaf++;
-                const Hit<float> sh = shape_hit(sc.t32, e->shape, r, tmin, hr.t);
-                if (any_hit) {
-                    if (sh.t > 0.0f && sh.t <= hr.t) { out = sh; return true; }
-                } else if (sh.t > 0.0f && sh.t < hr.t) { hr = sh; found = true; }
-            } else {
-                pending[np++] = e;
-            }
+            if (!slab_f32(sr, e->fmin, e->fmax, t0, entry_best)) continue;
+            if (e->leaf) leaves[nl++] = e; else pending[np++] = e;
+        }
+        // pass 2: hit leaf children intersected in ray order
+        for (int q = 0; q < nl; ++q) {
+            if (tc) tc->leaf++;
+            const Hit<float> sh = shape_hit(sc.t32, leaves[q]->shape, r, tmin, hr.t);
+            if (any_hit) {
+                if (sh.t > 0.0f && sh.t <= hr.t) { out = sh; return true; }
+            } else if (sh.t > 0.0f && sh.t < hr.t) { hr = sh; found = true; }
         }
         for (int i = np - 1; i >= 1; --i) stack.push_back(pending[i]);
         if (np > 0) { cur = pending[0]; continue; }

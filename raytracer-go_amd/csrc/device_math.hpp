@@ -1,0 +1,295 @@
+// Device-side arithmetic of the MI355X backend: r3.Vec helpers, Philox4x32-10, ray/shape
+// intersection, the ordered stack traversal of the flattened octree, textures and materials.
+//
+// All arithmetic is float32 with contraction OFF (the translation unit is built with
+// -ffp-contract=off and the pragma below): every expression is evaluated in the operation
+// order of the reference's float64 code, so that a float32 CPU restatement is bit-identical
+// (primitive IDs, t, camera rays).  The one deliberate FMA is the slab test, written with an
+// explicit fmaf on both sides.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace rtgo {
+
+#define RT_DEV __device__ __forceinline__
+
+struct f3 { float x, y, z; };
+RT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_DEV f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV f3 scale3(float f, f3 a) { return mk3(f * a.x, f * a.y, f * a.z); }
+RT_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV f3 cross3(f3 p, f3 q) { return mk3(p.y * q.z - p.z * q.y, p.z * q.x - p.x * q.z, p.x * q.y - p.y * q.x); }
+RT_DEV float norm3(f3 p) { return sqrtf(p.x * p.x + p.y * p.y + p.z * p.z); }
+// r3.Unit: Scale(1/Norm(p), p); Unit(0) = NaN vector
+RT_DEV f3 unit3(f3 p) {
+    if (p.x == 0.0f && p.y == 0.0f && p.z == 0.0f) { const float n = __builtin_nanf(""); return mk3(n, n, n); }
+    return scale3(1.0f / norm3(p), p);
+}
+RT_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+// ---- Philox4x32-10; counter = (pixel, sample, bounce*256+purpose, sub*256+try), key = seed ----
+struct u4 { uint32_t x, y, z, w; };
+RT_DEV u4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    u4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
+    return o;
+}
+enum { P_AA = 0, P_LENS = 1, P_FUZZ = 2, P_SCHLICK = 3, P_SHADOW = 4 };
+constexpr int kMaxTries = 64;
+struct RngKey { uint32_t k0, k1, pixel, sample; };
+RT_DEV u4 draw(const RngKey& k, uint32_t bounce, uint32_t purpose, uint32_t sub, uint32_t tr) {
+    return philox4x32(k.pixel, k.sample, bounce * 256u + purpose, sub * 256u + tr, k.k0, k.k1);
+}
+RT_DEV float u01(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
+
+// randomInUnitSphere, material.go:134-143 (rejection loop capped at kMaxTries)
+RT_DEV f3 random_in_unit_sphere(const RngKey& k, uint32_t bounce, uint32_t purpose, uint32_t sub) {
+    for (int tr = 0; tr < kMaxTries; ++tr) {
+        const u4 w = draw(k, bounce, purpose, sub, (uint32_t)tr);
+        const f3 p = sub3(scale3(2.0f, mk3(u01(w.x), u01(w.y), u01(w.z))), mk3(1.0f, 1.0f, 1.0f));
+        if (p.x * p.x + p.y * p.y + p.z * p.z < 1.0f) return p;
+    }
+    return mk3(0.0f, 0.0f, 0.0f);
+}
+
+// ---- scene tables in HBM ------------------------------------------------------------------
+struct DMaterial { int kind, texture; float color[3], spec[3], param; };
+struct DTexture { int kind, w, h; float c1[3], c2[3], cw, ch; const uint8_t* rgba; };
+struct DLight { int kind; float color[3], pos[3], look_dir[3], intensity, spec_intensity, cos_angle, decay; };
+struct DCamera { float u[3], v[3], origin[3], ll[3], hor[3], ver[3], lens; };
+
+constexpr uint32_t kLeaf = 0x80000000u;   // ChildRecord.w1
+constexpr uint32_t kPrimTriangle = 1u;    // prims[3i+2].y bits: bit0 triangle, bit1 single sided, material << 2
+constexpr uint32_t kPrimSingleSided = 2u;
+
+struct DScene {
+    const float4* recs;    // 2 float4 per child record: {min.xyz, max.x}, {max.y, max.z, w0, w1}
+    const float4* prims;   // 3 float4 per shape: tri {A, B.x}{B.yz, C.xy}{C.z, bits, -, -}; sphere {C, R}{-}{-, bits}
+    const DMaterial* materials;
+    const DTexture* textures;
+    const DLight* lights;
+    int n_lights, n_pos_lights;
+    uint32_t root_ref;
+};
+
+// ---- intersection: shape.go:47-78 (sphere), :117-163 (triangle); returns t or -1 ------------
+RT_DEV float sphere_hit(const float4 p0, f3 o, f3 d, float tmin, float tmax) {
+    const f3 oc = sub3(o, mk3(p0.x, p0.y, p0.z));
+    const float a = dot3(d, d);
+    const float b = dot3(oc, d);
+    const float c = dot3(oc, oc) - p0.w * p0.w;
+    const float disc = b * b - a * c;
+    if (disc > 0.0f) {
+        const float first = (-b - sqrtf(b * b - a * c)) / a;
+        if (first > tmin && first <= tmax) return first;
+        // shape.go:64: the "second root" repeats the first, so it can never add a hit
+    }
+    return -1.0f;
+}
+RT_DEV float triangle_hit(f3 A, f3 B, f3 C, bool single_sided, f3 o, f3 d, float tmin, float tmax) {
+    const f3 e1 = sub3(B, A), e2 = sub3(C, A);
+    const f3 pvec = cross3(d, e2);
+    const float det = dot3(e1, pvec);
+    if (single_sided && det < 0.0f) return -1.0f;
+    const float inv = 1.0f / det;
+    const f3 tvec = sub3(o, A);
+    const float u = dot3(tvec, pvec) * inv;
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    const f3 qvec = cross3(tvec, e1);
+    const float v = dot3(d, qvec) * inv;
+    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    const float t = dot3(e2, qvec) * inv;
+    if (t < tmin || t > tmax) return -1.0f;
+    return t;
+}
+RT_DEV float prim_hit(const DScene& S, uint32_t prim, f3 o, f3 d, float tmin, float tmax) {
+    const float4 p0 = S.prims[3 * (size_t)prim];
+    const float4 p2 = S.prims[3 * (size_t)prim + 2];
+    const uint32_t bits = __float_as_uint(p2.y);
+    if (bits & kPrimTriangle) {
+        const float4 p1 = S.prims[3 * (size_t)prim + 1];
+        return triangle_hit(mk3(p0.x, p0.y, p0.z), mk3(p0.w, p1.x, p1.y), mk3(p1.z, p1.w, p2.x),
+                            (bits & kPrimSingleSided) != 0, o, d, tmin, tmax);
+    }
+    return sphere_hit(p0, o, d, tmin, tmax);
+}
+
+// ---- ordered stack traversal --------------------------------------------------------------
+// Replaces bvh.trace (accelerationstructures.go:81-124): same nearest hit, found with a stack
+// instead of a heap.  Per node: (1) every present child's box is slab-tested against the best t
+// at node entry, in ray order k = 0..7, octant = k ^ sign mask; (2) hit leaf children are
+// intersected in that order, a hit is accepted iff t > 0 && t < best (strict: first found wins
+// ties, as :101); (3) hit inner children are pushed far-to-near and the nearest is entered.
+// ANY = shadow-ray form of doesReachLight (light.go:141-160): first accepted t <= tmax ends it.
+constexpr int kLdsStackDepth = 24;
+struct TraceStack {
+    uint32_t* lds;        // &s_stack[threadIdx.x], entries kBlock apart
+    uint32_t* overflow;   // &overflow[global thread], entries `stride` apart (worst-case depth)
+    uint32_t lds_stride, stride;
+    RT_DEV void put(int sp, uint32_t v) const {
+        if (sp < kLdsStackDepth) lds[sp * lds_stride] = v; else overflow[(size_t)(sp - kLdsStackDepth) * stride] = v;
+    }
+    RT_DEV uint32_t get(int sp) const {
+        return sp < kLdsStackDepth ? lds[sp * lds_stride] : overflow[(size_t)(sp - kLdsStackDepth) * stride];
+    }
+};
+
+template <bool ANY>
+RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tmin, float tmax, float* t_out, int* prim_out) {
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 oi = mk3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+    const uint32_t sign = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    float best = ANY ? tmax : 3.402823466e+38f;
+    int best_prim = -1;
+    uint32_t cur = S.root_ref;
+    int sp = 0;
+    for (;;) {
+        const uint32_t first = cur >> 8, present = cur & 0xffu;
+        uint32_t ref[8];
+        uint32_t leaf_mask = 0, inner_mask = 0;  // bit k = ray-order position
+        const float entry_best = best;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t oct = (uint32_t)k ^ sign;
+            ref[k] = 0;
+            if ((present >> oct) & 1u) {
+                const size_t idx = (size_t)first + __popc(present & ((1u << oct) - 1u));
+                const float4 a = S.recs[2 * idx], b = S.recs[2 * idx + 1];
+                float tn = 0.0f, tf = entry_best;
+                {
+                    const float lo = fmaf(a.x, inv.x, -oi.x), hi = fmaf(a.w, inv.x, -oi.x);
+                    tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+                }
+                {
+                    const float lo = fmaf(a.y, inv.y, -oi.y), hi = fmaf(b.x, inv.y, -oi.y);
+                    tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+                }
+                {
+                    const float lo = fmaf(a.z, inv.z, -oi.z), hi = fmaf(b.y, inv.z, -oi.z);
+                    tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+                }
+                if (tn <= tf) {
+                    ref[k] = __float_as_uint(b.z);
+                    if (__float_as_uint(b.w) & kLeaf) leaf_mask |= 1u << k; else inner_mask |= 1u << k;
+                }
+            }
+        }
+        while (leaf_mask) {
+            const int k = __ffs((int)leaf_mask) - 1;
+            leaf_mask &= leaf_mask - 1u;
+            uint32_t prim = ref[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) prim = (k == q) ? ref[q] : prim;
+            const float t = prim_hit(S, prim, o, d, tmin, best);
+            if (ANY) {
+                if (t > 0.0f && t <= best) { *t_out = t; *prim_out = (int)prim; return true; }
+            } else if (t > 0.0f && t < best) { best = t; best_prim = (int)prim; }
+        }
+        if (inner_mask) {
+            // far-to-near pushes of everything but the nearest, which is entered directly
+#pragma unroll
+            for (int k = 7; k >= 1; --k)
+                if (((inner_mask >> k) & 1u) && (inner_mask & ((1u << k) - 1u))) st.put(sp++, ref[k]);
+#pragma unroll
+            for (int k = 7; k >= 0; --k) cur = ((inner_mask >> k) & 1u) ? ref[k] : cur;
+            continue;
+        }
+        if (sp == 0) break;
+        cur = st.get(--sp);
+    }
+    *t_out = best;
+    *prim_out = best_prim;
+    return best_prim >= 0;
+}
+
+// ---- textures (texture.go:27-53) and UV maps (shape.go:100-105, 213-227) --------------------
+RT_DEV long long floor_to_int(float x) {
+    if (!(x == x)) return 0;
+    const float f = floorf(x);
+    if (f >= 9.0e18f) return 0x7fffffffffffffffLL;
+    if (f <= -9.0e18f) return (long long)0x8000000000000000ULL;
+    return (long long)f;
+}
+RT_DEV f3 texture_color(const DTexture& t, float u, float v) {
+    if (t.kind == RT_TEX_CHECKERS) {
+        const long long u2 = floor_to_int(u * t.cw), v2 = floor_to_int(v * t.ch);
+        return (((u2 + v2) & 1LL) == 0) ? ld3(t.c1) : ld3(t.c2);
+    }
+    const long long u2 = floor_to_int(u * (float)t.w), v2 = floor_to_int(v * (float)t.h);
+    uint32_t r = 0, g = 0, b = 0, a = 0;
+    if (u2 >= 0 && u2 < t.w && v2 >= 0 && v2 < t.h) {  // no clamp/wrap: outside = zero colour
+        const uchar4 px = reinterpret_cast<const uchar4*>(t.rgba)[(size_t)v2 * t.w + (size_t)u2];
+        r = px.x * 257u; g = px.y * 257u; b = px.z * 257u; a = px.w * 257u;
+    }
+    const float r256 = (float)r / 255.99f, g256 = (float)g / 255.99f, b256 = (float)b / 255.99f;
+    const float aa = (float)a / (255.99f * 255.99f);
+    const float a1 = aa < 1.0f ? aa : 1.0f;
+    return mk3((1.0f - a1) * 0.0f + (a1 * r256) / 255.99f,
+               (1.0f - a1) * 0.0f + (a1 * g256) / 255.99f,
+               (1.0f - a1) * 0.0f + (a1 * b256) / 255.99f);
+}
+struct PrimData { float4 p0, p1, p2; };
+RT_DEV PrimData load_prim(const DScene& S, int prim) {
+    PrimData P;
+    P.p0 = S.prims[3 * (size_t)prim]; P.p1 = S.prims[3 * (size_t)prim + 1]; P.p2 = S.prims[3 * (size_t)prim + 2];
+    return P;
+}
+RT_DEV void texture_map(const PrimData& P, f3 point, float* u, float* v) {
+    const uint32_t bits = __float_as_uint(P.p2.y);
+    const float kPi = 3.14159265358979323846f;
+    if (!(bits & kPrimTriangle)) {  // shape.go:100-105
+        const f3 q = sub3(point, mk3(P.p0.x, P.p0.y, P.p0.z));
+        const float theta = atan2f(-1.0f * q.z, q.x);
+        const float phi = acosf(-1.0f * q.y / P.p0.w);
+        *u = (theta + kPi) / (2.0f * kPi);
+        *v = phi / kPi;
+    } else {  // shape.go:213-227: u = 1 - v(=0, the unset named result) - w
+        const f3 A = mk3(P.p0.x, P.p0.y, P.p0.z), B = mk3(P.p0.w, P.p1.x, P.p1.y), C = mk3(P.p1.z, P.p1.w, P.p2.x);
+        const f3 v0 = sub3(B, A), v1 = sub3(C, A), v2 = sub3(point, A);
+        const float d00 = dot3(v0, v0), d01 = dot3(v0, v1), d11 = dot3(v1, v1), d20 = dot3(v2, v0), d21 = dot3(v2, v1);
+        const float denom = d00 * d11 - d01 * d01;
+        const float w = (d00 * d21 - d01 * d20) / denom;
+        *u = 1.0f - 0.0f - w;
+        *v = (d11 * d20 - d01 * d21) / denom;
+    }
+}
+// hitRecord.normal: shape.go:59 (sphere: (p - C)/R), :122 (triangle: Unit(e1 x e2), never flipped)
+RT_DEV f3 prim_normal(const PrimData& P, f3 o, f3 d, float t) {
+    const uint32_t bits = __float_as_uint(P.p2.y);
+    if (!(bits & kPrimTriangle))
+        return scale3(1.0f / P.p0.w, sub3(add3(o, scale3(t, d)), mk3(P.p0.x, P.p0.y, P.p0.z)));
+    const f3 A = mk3(P.p0.x, P.p0.y, P.p0.z), B = mk3(P.p0.w, P.p1.x, P.p1.y), C = mk3(P.p1.z, P.p1.w, P.p2.x);
+    return unit3(cross3(sub3(B, A), sub3(C, A)));
+}
+
+// ---- material helpers (material.go:145-172) -------------------------------------------------
+RT_DEV f3 reflected(f3 v, f3 n) { return unit3(sub3(v, scale3(2.0f * dot3(v, n), n))); }
+RT_DEV f3 refracted(f3 v, f3 n, float eta) {
+    const f3 uv = unit3(v);
+    const float dt = dot3(scale3(-1.0f, uv), n);
+    const float cos_theta = (1.0f < dt) ? 1.0f : dt;  // math.Min(dt, 1.0)
+    const f3 perp = scale3(eta, add3(uv, scale3(cos_theta, n)));
+    // material.go:153 precedence quirk kept: |1 - x^2 + y^2 + z^2|
+    const f3 par = scale3(-sqrtf(fabsf(1.0f - perp.x * perp.x + perp.y * perp.y + perp.z * perp.z)), n);
+    return unit3(add3(perp, par));
+}
+RT_DEV float schlick(float cosine, float ri) {
+    float r0 = (1.0f - ri) / (1.0f + ri);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * powf(1.0f - cosine, 5.0f);
+}
+RT_DEV float saturate(float i) { return i > 1.0f ? 1.0f : (i < 0.0f ? 0.0f : i); }
+RT_DEV float min1(float x) { return x < 1.0f ? x : 1.0f; }  // std::min(1, x) / math.Min(1.0, x)
+
+}  // namespace rtgo

@@ -1,0 +1,220 @@
+// See octree.hpp.  Host code only (no HIP): float64 throughout, like the reference.
+#include "octree.hpp"
+
+#include <cfloat>
+#include <cmath>
+#include <deque>
+
+namespace rtgo {
+namespace {
+
+// The reference jitters centroids with Go's global math/rand (accelerationstructures.go:267);
+// that stream is unseeded and shared, so any fixed stream is an equally valid draw.  This one
+// is splitmix64 from a fixed seed (documented in DESIGN.md so the CPU oracle can use the same).
+struct Jitter {
+    uint64_t s = 0x6A09E667F3BCC909ull;
+    double next() {
+        s += 0x9E3779B97F4A7C15ull;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    }
+};
+
+constexpr double kJitterFactor = 0.0000000001;  // bvhCentroidJitterFactor, raytracer.go:12
+
+// computeSquareBounds: shape.go:91-93 (sphere), :183-207 (triangle)
+void shape_bounds(const rt_shape& s, double lo[3], double hi[3]) {
+    if (s.kind == RT_SHAPE_SPHERE) {
+        const double r = s.b.x;
+        lo[0] = s.a.x - r; lo[1] = s.a.y - r; lo[2] = s.a.z - r;
+        hi[0] = s.a.x + r; hi[1] = s.a.y + r; hi[2] = s.a.z + r;
+        return;
+    }
+    const double px[3] = {s.a.x, s.b.x, s.c.x}, py[3] = {s.a.y, s.b.y, s.c.y}, pz[3] = {s.a.z, s.b.z, s.c.z};
+    lo[0] = std::fmin(std::fmin(px[0], px[1]), px[2]); hi[0] = std::fmax(std::fmax(px[0], px[1]), px[2]);
+    lo[1] = std::fmin(std::fmin(py[0], py[1]), py[2]); hi[1] = std::fmax(std::fmax(py[0], py[1]), py[2]);
+    lo[2] = std::fmin(std::fmin(pz[0], pz[1]), pz[2]); hi[2] = std::fmax(std::fmax(pz[0], pz[1]), pz[2]);
+}
+
+// centroid: shape.go:95-97 (sphere), :209-211 (triangle: Scale(1/3.0, A + (B + C)))
+void shape_centroid(const rt_shape& s, double c[3]) {
+    if (s.kind == RT_SHAPE_SPHERE) { c[0] = s.a.x; c[1] = s.a.y; c[2] = s.a.z; return; }
+    const double k = 1 / 3.0;
+    c[0] = k * (s.a.x + (s.b.x + s.c.x));
+    c[1] = k * (s.a.y + (s.b.y + s.c.y));
+    c[2] = k * (s.a.z + (s.b.z + s.c.z));
+}
+
+// getBvhQuadrantIndex: accelerationstructures.go:266-279 (bit0 = X, bit1 = Y, bit2 = Z)
+int octant_of(const rt_shape& s, const HostNode& cell, Jitter& rng) {
+    double c[3];
+    shape_centroid(s, c);
+    const double jx = rng.next(), jy = rng.next(), jz = rng.next();
+    c[0] += kJitterFactor * jx; c[1] += kJitterFactor * jy; c[2] += kJitterFactor * jz;
+    int idx = 0;
+    if (c[0] > cell.lo[0] + (cell.hi[0] - cell.lo[0]) / 2) idx += 1;
+    if (c[1] > cell.lo[1] + (cell.hi[1] - cell.lo[1]) / 2) idx += 2;
+    if (c[2] > cell.lo[2] + (cell.hi[2] - cell.lo[2]) / 2) idx += 4;
+    return idx;
+}
+
+// splitBvhQuadrant: accelerationstructures.go:282-353
+void split_cell(std::vector<HostNode>& nodes, int32_t at) {
+    const int32_t base = (int32_t)nodes.size();
+    double lo[3], hi[3], half[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = nodes[at].lo[a]; hi[a] = nodes[at].hi[a];
+        half[a] = (hi[a] - lo[a]) / 2;
+    }
+    for (int o = 0; o < 8; ++o) {
+        HostNode c;
+        for (int a = 0; a < 3; ++a) {
+            const bool upper = (o >> a) & 1;
+            c.lo[a] = upper ? lo[a] + half[a] : lo[a];
+            c.hi[a] = upper ? hi[a] : lo[a] + half[a];
+        }
+        nodes.push_back(c);
+    }
+    nodes[at].child_base = base;
+}
+
+float round_down_f32(double x) {
+    float f = (float)x;
+    if ((double)f > x) f = std::nextafterf(f, -INFINITY);
+    return f;
+}
+float round_up_f32(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+
+// Skip nodes that have exactly one non-empty child (same box as that child after the refit).
+int32_t skip_chain(const std::vector<HostNode>& nodes, int32_t n) {
+    while (nodes[n].child_base >= 0) {
+        int32_t only = -1, cnt = 0;
+        for (int o = 0; o < 8; ++o) {
+            const int32_t c = nodes[n].child_base + o;
+            if (!nodes[c].empty) { only = c; ++cnt; }
+        }
+        if (cnt != 1) break;
+        n = only;
+    }
+    return n;
+}
+
+}  // namespace
+
+std::vector<HostNode> build_octree(const rt_shape* shapes, int64_t n) {
+    std::vector<HostNode> nodes;
+    nodes.reserve((size_t)(n * 4 + 16));
+    HostNode root;
+    // accelerationstructures.go:29-42: union of all shape bounds, widened by the max jitter
+    for (int a = 0; a < 3; ++a) { root.lo[a] = DBL_MAX; root.hi[a] = -9223372036854775808.0; }
+    for (int64_t i = 0; i < n; ++i) {
+        double lo[3], hi[3];
+        shape_bounds(shapes[i], lo, hi);
+        for (int a = 0; a < 3; ++a) { root.lo[a] = std::fmin(root.lo[a], lo[a]); root.hi[a] = std::fmax(root.hi[a], hi[a]); }
+    }
+    for (int a = 0; a < 3; ++a) { root.lo[a] -= kJitterFactor * 1; root.hi[a] += kJitterFactor * 1; }
+    nodes.push_back(root);
+
+    // accelerationstructures.go:57-60 + addToBVH :226-255.  The recursion of the reference is
+    // unrolled: after a split all 8 children are empty, so the evicted shape lands in its child
+    // in one step (its 3 jitter draws come first, as in the reference), then the new shape
+    // keeps descending.
+    Jitter rng;
+    for (int64_t i = 0; i < n; ++i) {
+        int32_t cur = 0;
+        for (;;) {
+            if (nodes[cur].child_base < 0) {
+                if (nodes[cur].shape < 0) { nodes[cur].shape = (int32_t)i; break; }
+                const int32_t evicted = nodes[cur].shape;
+                nodes[cur].shape = -1;
+                split_cell(nodes, cur);
+                const int32_t dst = nodes[cur].child_base + octant_of(shapes[evicted], nodes[cur], rng);
+                nodes[dst].shape = evicted;
+            }
+            cur = nodes[cur].child_base + octant_of(shapes[i], nodes[cur], rng);
+        }
+    }
+
+    // recomputeNodeBounds (:189-211).  Children are always appended after their parent, so a
+    // reverse sweep is a post-order walk.  `empty` stands for the reference's
+    // (+MaxFloat64, float64(MinInt64)) sentinel box that destroyUselessNodes (:213-224) prunes.
+    for (int64_t k = (int64_t)nodes.size() - 1; k >= 0; --k) {
+        HostNode& nd = nodes[k];
+        if (nd.child_base < 0) {
+            nd.empty = nd.shape < 0;
+            if (!nd.empty) shape_bounds(shapes[nd.shape], nd.lo, nd.hi);
+            continue;
+        }
+        nd.empty = true;
+        for (int a = 0; a < 3; ++a) { nd.lo[a] = DBL_MAX; nd.hi[a] = -9223372036854775808.0; }
+        for (int o = 0; o < 8; ++o) {
+            const HostNode& c = nodes[nd.child_base + o];
+            if (c.empty) continue;
+            nd.empty = false;
+            for (int a = 0; a < 3; ++a) { nd.lo[a] = std::fmin(nd.lo[a], c.lo[a]); nd.hi[a] = std::fmax(nd.hi[a], c.hi[a]); }
+        }
+    }
+    return nodes;
+}
+
+bool flatten_octree(const std::vector<HostNode>& nodes, FlatTree* out, const char** err) {
+    out->records.clear();
+    out->root_ref = 0; out->n_inner = 0; out->depth = 0; out->stack_bound = 1;
+    if (nodes.empty() || nodes[0].empty) return true;  // no shapes: present mask 0 => every ray misses
+
+    struct Pending { int32_t node; int64_t patch; int32_t level; };  // patch = record whose w0 names this block
+    std::deque<Pending> queue;
+    const int32_t root = skip_chain(nodes, 0);
+    if (nodes[root].child_base < 0) {
+        // A single shape: synthetic root block with one leaf record in octant 0.
+        ChildRecord r;
+        for (int a = 0; a < 3; ++a) { r.bmin[a] = round_down_f32(nodes[root].lo[a]); r.bmax[a] = round_up_f32(nodes[root].hi[a]); }
+        r.w0 = (uint32_t)nodes[root].shape; r.w1 = kLeafFlag;
+        out->records.push_back(r);
+        out->root_ref = (0u << 8) | 1u;
+        out->n_inner = 1; out->depth = 1; out->stack_bound = 8;
+        return true;
+    }
+    queue.push_back({root, -1, 1});
+    while (!queue.empty()) {
+        const Pending p = queue.front();
+        queue.pop_front();
+        const HostNode& nd = nodes[p.node];
+        const int64_t first = (int64_t)out->records.size();
+        uint32_t present = 0;
+        for (int o = 0; o < 8; ++o) {
+            const int32_t c = nd.child_base + o;
+            if (nodes[c].empty) continue;
+            present |= 1u << o;
+            const int32_t e = skip_chain(nodes, c);
+            ChildRecord r;
+            for (int a = 0; a < 3; ++a) { r.bmin[a] = round_down_f32(nodes[e].lo[a]); r.bmax[a] = round_up_f32(nodes[e].hi[a]); }
+            if (nodes[e].child_base < 0) {
+                r.w0 = (uint32_t)nodes[e].shape; r.w1 = kLeafFlag;
+            } else {
+                r.w0 = 0; r.w1 = 0;
+                queue.push_back({e, (int64_t)out->records.size(), p.level + 1});
+            }
+            out->records.push_back(r);
+        }
+        if ((int64_t)out->records.size() > kMaxChildRecords) {
+            *err = "scene too large: the flattened octree exceeds 2^24 child records";
+            return false;
+        }
+        const uint32_t ref = ((uint32_t)first << 8) | present;
+        if (p.patch < 0) out->root_ref = ref; else out->records[(size_t)p.patch].w0 = ref;
+        out->n_inner++;
+        if (p.level > out->depth) out->depth = p.level;
+    }
+    out->stack_bound = 7 * out->depth + 1;
+    return true;
+}
+
+}  // namespace rtgo

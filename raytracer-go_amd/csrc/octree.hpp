@@ -1,0 +1,54 @@
+// Host-side acceleration structure of the MI355X backend.
+//
+// build_octree() restates NewBoundingVolumeHierarchy (reference
+// raytracer/accelerationstructures.go:27-65): sequential insertion octree with one shape per
+// leaf (addToBVH :226-255, getBvhQuadrantIndex :266-279, splitBvhQuadrant :282-353), then the
+// bottom-up tight refit and the pruning of empty children (recomputeNodeBounds :189-211,
+// destroyUselessNodes :213-224).
+//
+// flatten_octree() turns that tree into the arrays the HIP traversal reads from HBM:
+//   - every node with >= 2 non-empty children becomes one contiguous block of 32-byte child
+//     records {fp32 AABB rounded outward, w0, w1}, children in octant order, empty ones
+//     omitted; blocks are laid out breadth-first so the top of the tree is contiguous;
+//   - a chain of nodes with a single non-empty child is dropped: after the refit such a node
+//     has exactly its child's box, so removing it cannot change any hit;
+//   - inner child : w0 = (first record of its block << 8) | 8-bit octant-present mask, w1 = 0
+//     leaf child  : w0 = shape index (= position in Scene.Shapes), w1 = kLeafFlag.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/rtgo.h"
+
+namespace rtgo {
+
+constexpr uint32_t kLeafFlag = 0x80000000u;
+constexpr int64_t kMaxChildRecords = (int64_t)1 << 24;  // w0 keeps 24 bits for the block index
+
+struct HostNode {
+    double lo[3], hi[3];  // cell bounds while inserting, tight bounds after refit()
+    int32_t shape = -1;   // leaf payload, -1 = empty
+    int32_t child_base = -1;  // index of the first of 8 consecutive children, -1 = leaf
+    bool empty = true;    // after refit(): subtree holds no shape
+};
+
+struct ChildRecord {  // 32 bytes, read by the kernels as two float4
+    float bmin[3];
+    float bmax[3];
+    uint32_t w0, w1;
+};
+
+struct FlatTree {
+    std::vector<ChildRecord> records;
+    uint32_t root_ref = 0;  // (first << 8) | present of the root block
+    int64_t n_inner = 0;    // blocks
+    int32_t depth = 0;      // levels of blocks below the root (root block = 1)
+    int32_t stack_bound = 1;
+};
+
+// shapes: desc->shapes[0..n). Returns nodes[0] = root.
+std::vector<HostNode> build_octree(const rt_shape* shapes, int64_t n);
+// Returns false (and sets *err) if the tree exceeds kMaxChildRecords.
+bool flatten_octree(const std::vector<HostNode>& nodes, FlatTree* out, const char** err);
+
+}  // namespace rtgo

@@ -1,0 +1,925 @@
+// librtgo_hip.so — wavefront path tracer for MI355X (gfx950) behind include/rtgo.h.
+//
+// Stages per batch of (pixel, sample) paths, all on one HIP stream:
+//   raygen     camera.go:37-55 + raytracer.go:113-116   1 lane / path
+//   extend     accelerationstructures.go:81-124          1 lane / live ray, ordered stack traversal
+//   shade      raytracer.go:143-161 + material.go:34-70  1 lane / hit; Metal/Dielectric continue,
+//                                                         PhongBlinn hits go to the phong queue
+//   shadow     material.go:76-82 + light.go:93-160       1 lane / (hit, light, repetition); any-hit
+//   phong      material.go:83-131                         1 lane / PhongBlinn hit
+//   accumulate raytracer.go:117-119                       1 lane / pixel (fixed-order sample sum)
+//   resolve    raytracer.go:93-96,125                     1 lane / pixel -> RGBA8
+// Queues are compacted with a 64-lane ballot + popcount prefix and one atomic per wavefront.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtgo.h"
+#include "device_math.hpp"
+#include "octree.hpp"
+
+#pragma clang fp contract(off)
+
+using namespace rtgo;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxGridBlocks = 2048;  // 256 CUs x 8: persistent grid-stride kernels
+constexpr int64_t kDefaultMaxPaths = (int64_t)1 << 23;
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// Batch geometry: which (pixel, sample) a path slot is
+// ------------------------------------------------------------------------------------------
+struct Batch {
+    int W, H;
+    int tile, tiles_x;         // square tiles of `tile` pixels (multiple of 8), row-major tile grid
+    int rank, world, by_tiles; // by_tiles: this rank owns tiles k with k % world == rank
+    long long lp0;             // first local pixel of the batch
+    int npix, ns, s0;          // local pixels, samples per pixel in this batch, first sample index
+    int max_depth, reps;
+    uint32_t k0, k1;           // Philox key
+};
+
+// local pixel -> (column x, output row); false when the tile cell lies outside the image
+RT_DEV bool pixel_of(const Batch& B, long long lp, int* x, int* row) {
+    const int tt = B.tile * B.tile;
+    const long long tj = lp / tt;
+    const int w = (int)(lp - tj * tt);
+    const long long k = B.by_tiles ? tj * B.world + B.rank : tj;
+    const int tx = (int)(k % B.tiles_x), ty = (int)(k / B.tiles_x);
+    const int sub_per_row = B.tile >> 3;
+    const int b = w >> 6, i = w & 63;  // 8x8 sub-blocks keep a wavefront's pixels together
+    *x = tx * B.tile + (b % sub_per_row) * 8 + (i & 7);
+    *row = ty * B.tile + (b / sub_per_row) * 8 + (i >> 3);
+    return *x < B.W && *row < B.H;
+}
+
+struct Work {
+    float4* ray_o;   // {origin.xyz, hit t}
+    float4* ray_d;   // {direction.xyz, bits of hit shape index (-1 = miss)}
+    float4* thr;     // path throughput (product of attenuations)
+    float4* rad;     // terminal radiance of the path (written once)
+    uint32_t* queue[2];
+    uint32_t* phong_queue;
+    uint32_t* vis;   // visible-repetition count per (phong hit, positional light)
+    uint32_t* counters;  // [0..D] ray-queue sizes per bounce, [D+1..2D] phong-queue sizes, [2D+2..3] shadow rays (u64)
+    uint32_t* overflow;  // traversal stack spill
+    uint32_t overflow_stride;
+};
+
+// ballot + popcount-prefix compaction: one atomic per wavefront
+RT_DEV uint32_t wave_push(uint32_t* counter, bool pred) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    const int lane = (int)__lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// raytracer.go:114-116 + camera.go:37-55
+RT_DEV void camera_ray(const DCamera& cam, int W, int H, int i, int j, const RngKey& key, f3* o, f3* d) {
+    const u4 aa = draw(key, 0, P_AA, 0, 0);
+    const float u = ((float)i + u01(aa.x)) / (float)W;
+    const float v = ((float)j + u01(aa.y)) / (float)H;
+    f3 disk = mk3(0.0f, 0.0f, 0.0f);
+    for (int tr = 0; tr < kMaxTries; ++tr) {  // randomInUnitDisk runs even when the aperture is 0
+        const u4 w = draw(key, 0, P_LENS, 0, (uint32_t)tr);
+        const f3 p = sub3(scale3(2.0f, mk3(u01(w.x), u01(w.y), 0.0f)), mk3(1.0f, 1.0f, 0.0f));
+        if (dot3(p, p) < 1.0f) { disk = p; break; }
+    }
+    const f3 rd = scale3(cam.lens, disk);
+    const f3 offset = add3(scale3(rd.x, ld3(cam.u)), scale3(rd.y, ld3(cam.v)));
+    *o = add3(ld3(cam.origin), offset);
+    *d = unit3(sub3(sub3(add3(add3(ld3(cam.ll), scale3(u, ld3(cam.hor))), scale3(v, ld3(cam.ver))), ld3(cam.origin)), offset));
+}
+
+__global__ __launch_bounds__(kBlock) void k_raygen(Batch B, DCamera cam, Work Wk) {
+    const long long slot = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long total = (long long)B.npix * B.ns;
+    bool valid = slot < total;
+    int x = 0, row = 0, smp = 0;
+    if (valid) {
+        const long long lpl = slot / B.ns;
+        smp = B.s0 + (int)(slot - lpl * B.ns);
+        valid = pixel_of(B, B.lp0 + lpl, &x, &row);
+    }
+    if (valid) {
+        const RngKey key{B.k0, B.k1, (uint32_t)(row * B.W + x), (uint32_t)smp};
+        f3 o, d;
+        camera_ray(cam, B.W, B.H, x, B.H - 1 - row, key, &o, &d);
+        Wk.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.0f);
+        Wk.ray_d[slot] = make_float4(d.x, d.y, d.z, __int_as_float(-1));
+        Wk.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    }
+    if (slot < total) Wk.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const uint32_t at = wave_push(&Wk.counters[0], valid);
+    if (valid) Wk.queue[0][at] = (uint32_t)slot;
+}
+
+__global__ __launch_bounds__(kBlock) void k_extend(DScene S, Work Wk, const uint32_t* queue, uint32_t n) {
+    __shared__ uint32_t s_stack[kLdsStackDepth * kBlock];
+    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t gstride = gridDim.x * kBlock;
+    const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride};
+    for (uint32_t i = gtid; i < n; i += gstride) {
+        const uint32_t slot = queue[i];
+        const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
+        float t; int prim;
+        traverse<false>(S, st, mk3(ro.x, ro.y, ro.z), mk3(rdv.x, rdv.y, rdv.z), 0.0f, 0.0f, &t, &prim);
+        Wk.ray_o[slot].w = t;
+        Wk.ray_d[slot].w = __int_as_float(prim);
+    }
+}
+
+// color() (raytracer.go:135-162) one bounce at a time + Standard/Metal/Dielectric scatter
+__global__ __launch_bounds__(kBlock) void k_shade(DScene S, Batch B, Work Wk, const uint32_t* queue, uint32_t n,
+                                                  uint32_t* next_queue, int bounce) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    bool cont = false, phong = false;
+    uint32_t slot = 0;
+    if (i < n) {
+        slot = queue[i];
+        const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
+        const int prim = __float_as_int(rdv.w);
+        if (prim >= 0) {  // miss: background (0,0,0), raytracer.go:161
+            const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rdv.x, rdv.y, rdv.z);
+            const float t = ro.w;
+            const PrimData P = load_prim(S, prim);
+            const DMaterial m = S.materials[__float_as_uint(P.p2.y) >> 2];
+            const f3 p = add3(o, scale3(t, d));
+            const float4 th = Wk.thr[slot];
+            if (m.kind == RT_MAT_STANDARD) {  // material.go:34-41: unlit terminal colour
+                f3 col = ld3(m.color);
+                if (m.texture >= 0) {
+                    float u, v;
+                    texture_map(P, p, &u, &v);
+                    col = texture_color(S.textures[m.texture], u, v);
+                }
+                Wk.rad[slot] = make_float4(th.x * col.x, th.y * col.y, th.z * col.z, 0.0f);
+            } else if (m.kind == RT_MAT_PHONGBLINN) {
+                phong = true;
+            } else {
+                const f3 nrm = prim_normal(P, o, d, t);
+                const long long lpl = (long long)slot / B.ns;
+                int x, row;
+                pixel_of(B, B.lp0 + lpl, &x, &row);
+                const RngKey key{B.k0, B.k1, (uint32_t)(row * B.W + x), (uint32_t)(B.s0 + (int)(slot - lpl * B.ns))};
+                if (m.kind == RT_MAT_METAL) {  // material.go:43-50
+                    const float fuzz = m.param < 1.0f ? m.param : 1.0f;
+                    const f3 refl = reflected(d, nrm);
+                    const f3 rnd = random_in_unit_sphere(key, (uint32_t)bounce, P_FUZZ, 0);
+                    if (dot3(refl, nrm) > 0.0f) {  // back face: terminal (0,0,0)
+                        const f3 nd = add3(refl, scale3(fuzz, rnd));  // not re-normalised
+                        Wk.ray_o[slot] = make_float4(p.x, p.y, p.z, 0.0f);  // origin = p, no epsilon
+                        Wk.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, __int_as_float(-1));
+                        Wk.thr[slot] = make_float4(th.x * m.color[0], th.y * m.color[1], th.z * m.color[2], 0.0f);
+                        cont = true;
+                    }
+                } else {  // Dielectric, material.go:52-70
+                    const float ratio = dot3(d, nrm) > 0.0f ? m.param : 1.0f / m.param;
+                    const float dt = dot3(scale3(-1.0f, d), nrm);
+                    const float cos_theta = (1.0f < dt) ? 1.0f : dt;
+                    const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                    const bool cannot = ratio * sin_theta > 1.0f;
+                    f3 dir;
+                    if (cannot || schlick(cos_theta, ratio) > u01(draw(key, (uint32_t)bounce, P_SCHLICK, 0, 0).x))
+                        dir = reflected(d, nrm);
+                    else
+                        dir = refracted(d, nrm, ratio);
+                    const f3 np = add3(p, scale3(0.00001f, dir));
+                    Wk.ray_o[slot] = make_float4(np.x, np.y, np.z, 0.0f);
+                    Wk.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, __int_as_float(-1));
+                    Wk.thr[slot] = make_float4(th.x * 1.0f, th.y * 1.0f, th.z * 1.0f, 0.0f);
+                    cont = true;
+                }
+            }
+        }
+    }
+    // a ray scattered at the last allowed depth can only return black (raytracer.go:145)
+    cont = cont && (bounce + 1 < B.max_depth);
+    const uint32_t at = wave_push(&Wk.counters[bounce + 1], cont);
+    if (cont) next_queue[at] = slot;
+    const uint32_t pat = wave_push(&Wk.counters[B.max_depth + 1 + bounce], phong);
+    if (phong) Wk.phong_queue[pat] = slot;
+}
+
+// One lane per (PhongBlinn hit, positional light, repetition lane).  group = lanes per (hit, light):
+// a power of two <= 64; each lane runs repetitions r, r+group, ...  The visible repetitions of a
+// (hit, light) are counted with a ballot popcount: integer, so the result has no summation order.
+__global__ __launch_bounds__(kBlock) void k_shadow(DScene S, Batch B, Work Wk, uint32_t n_hits, int bounce,
+                                                   int group, int group_shift) {
+    __shared__ uint32_t s_stack[kLdsStackDepth * kBlock];
+    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t gstride = gridDim.x * kBlock;
+    const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride};
+    const unsigned long long total = (unsigned long long)n_hits * S.n_pos_lights * group;
+    const unsigned long long rounds = (total + gstride - 1) / gstride;
+    const int lane = (int)__lane_id();
+    const int gbase = lane & ~(group - 1);
+    const unsigned long long gmask = group == 64 ? ~0ull : (((1ull << group) - 1ull) << gbase);
+    unsigned long long launched = 0;
+    for (unsigned long long it = 0; it < rounds; ++it) {
+        const unsigned long long idx = it * gstride + gtid;
+        const bool active = idx < total;
+        uint32_t r = 0, hit_i = 0, lp = 0;
+        f3 p = mk3(0, 0, 0);
+        RngKey key{B.k0, B.k1, 0, 0};
+        DLight L;
+        L.kind = 0;
+        if (active) {
+            r = (uint32_t)(idx & (unsigned long long)(group - 1));
+            const unsigned long long hl = idx >> group_shift;
+            hit_i = (uint32_t)(hl / S.n_pos_lights);
+            lp = (uint32_t)(hl - (unsigned long long)hit_i * S.n_pos_lights);
+            const uint32_t slot = Wk.phong_queue[hit_i];
+            const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
+            p = add3(mk3(ro.x, ro.y, ro.z), scale3(ro.w, mk3(rdv.x, rdv.y, rdv.z)));
+            const long long lpl = (long long)slot / B.ns;
+            int x, row;
+            pixel_of(B, B.lp0 + lpl, &x, &row);
+            key.pixel = (uint32_t)(row * B.W + x);
+            key.sample = (uint32_t)(B.s0 + (int)(slot - lpl * B.ns));
+            // positional light #lp
+            int seen = -1;
+            for (int q = 0; q < S.n_lights; ++q) {
+                if (S.lights[q].kind != RT_LIGHT_AMBIENT && ++seen == (int)lp) { L = S.lights[q]; break; }
+            }
+        }
+        uint32_t count = 0;
+        const int iters = (B.reps + group - 1) >> group_shift;  // > 1 only when reps > 64
+        for (int itn = 0; itn < iters; ++itn) {
+            // every lane of the wavefront runs the same number of rounds so the ballot is convergent
+            const uint32_t rep = r + (uint32_t)itn * (uint32_t)group;
+            bool vis = false;
+            if (active && rep < (uint32_t)B.reps) {
+                const f3 jit = scale3(0.25f, random_in_unit_sphere(key, (uint32_t)bounce, P_SHADOW, lp * (uint32_t)B.reps + rep));
+                const f3 shifted = add3(ld3(L.pos), jit);  // light.go:94 / :123
+                bool in_cone = true;
+                if (L.kind == RT_LIGHT_SPOT)  // light.go:126-130 as cos(angle) >= cos(Angle)
+                    in_cone = dot3(ld3(L.look_dir), unit3(sub3(p, shifted))) >= L.cos_angle;
+                if (in_cone) {
+                    ++launched;
+                    const f3 ld = sub3(shifted, p);  // doesReachLight, light.go:141-160
+                    const float dist = norm3(ld);
+                    float t; int prim;
+                    vis = !traverse<true>(S, st, p, scale3(1.0f / dist, ld), 0.01f, dist, &t, &prim);
+                }
+            }
+            const unsigned long long m = __ballot(vis);
+            count += (uint32_t)__popcll(m & gmask);
+        }
+        if (active && r == 0) Wk.vis[(size_t)hit_i * S.n_pos_lights + lp] = count;
+    }
+    // shadow rays actually traced: one 64-bit atomic per wavefront
+    for (int off = 32; off > 0; off >>= 1) launched += __shfl_down(launched, off);
+    if (lane == 0 && launched) atomicAdd(reinterpret_cast<unsigned long long*>(Wk.counters + 2 * B.max_depth + 2), launched);
+}
+
+// PhongBlinn.scatter (material.go:73-132) given the visible-repetition counts
+__global__ __launch_bounds__(kBlock) void k_phong(DScene S, Batch B, Work Wk, uint32_t n_hits) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_hits) return;
+    const uint32_t slot = Wk.phong_queue[i];
+    const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
+    const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rdv.x, rdv.y, rdv.z);
+    const float t = ro.w;
+    const int prim = __float_as_int(rdv.w);
+    const PrimData P = load_prim(S, prim);
+    const DMaterial m = S.materials[__float_as_uint(P.p2.y) >> 2];
+    const f3 p = add3(o, scale3(t, d));
+    const f3 nrm = prim_normal(P, o, d, t);
+    f3 mc = ld3(m.color);
+    if (m.texture >= 0) {
+        float u, v;
+        texture_map(P, p, &u, &v);
+        mc = texture_color(S.textures[m.texture], u, v);
+    }
+    f3 c = mk3(0.0f, 0.0f, 0.0f);
+    int lp = 0;
+    for (int q = 0; q < S.n_lights; ++q) {
+        const DLight L = S.lights[q];
+        if (L.kind != RT_LIGHT_AMBIENT) {
+            const uint32_t cnt = Wk.vis[(size_t)i * S.n_pos_lights + lp];
+            ++lp;
+            if (cnt == 0) continue;
+            const f3 l2p = sub3(ld3(L.pos), p);  // un-jittered position, material.go:83-84
+            const f3 ldir = unit3(l2p);
+            const float d2 = l2p.x * l2p.x + l2p.y * l2p.y + l2p.z * l2p.z;
+            float decay = L.decay * d2;
+            if (decay <= 1.0f) decay = 1.0f;
+            const float inten = saturate(dot3(nrm, ldir));
+            const f3 diff = scale3(inten * L.intensity / decay, mk3(mc.x * L.color[0], mc.y * L.color[1], mc.z * L.color[2]));
+            const f3 h = unit3(add3(ldir, d));  // material.go:107: ray direction, not view direction
+            const float si = powf(saturate(dot3(nrm, h)), m.param);
+            const f3 spec = scale3(si * L.spec_intensity / decay, mk3(m.spec[0] * L.color[0], m.spec[1] * L.color[1], m.spec[2] * L.color[2]));
+            const f3 comb = mk3(min1(diff.x + spec.x), min1(diff.y + spec.y), min1(diff.z + spec.z));
+            const float w = (float)cnt / (float)B.reps;  // cnt visible repetitions, each worth comb / reps
+            c = add3(c, scale3(w, comb));
+        } else {
+            c = add3(c, scale3(L.intensity, ld3(L.color)));  // material.go:125
+        }
+    }
+    c = mk3(min1(c.x), min1(c.y), min1(c.z));  // material.go:128-130
+    const float4 th = Wk.thr[slot];
+    Wk.rad[slot] = make_float4(th.x * c.x, th.y * c.y, th.z * c.z, 0.0f);
+}
+
+// raytracer.go:117: pixel += color(...), samples summed in index order (deterministic)
+__global__ __launch_bounds__(kBlock) void k_accumulate(Batch B, Work Wk, float* accum) {
+    const long long lpl = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (lpl >= B.npix) return;
+    int x, row;
+    if (!pixel_of(B, B.lp0 + lpl, &x, &row)) return;
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    const float4* r = Wk.rad + lpl * B.ns;
+    for (int k = 0; k < B.ns; ++k) { const float4 v = r[k]; sx += v.x; sy += v.y; sz += v.z; }
+    float* a = accum + ((size_t)row * B.W + x) * 3;
+    a[0] += sx; a[1] += sy; a[2] += sz;
+}
+
+// raytracer.go:119 (/spp) + :93-96 (uint8(min(255, c*255.99)), alpha 255)
+__global__ __launch_bounds__(kBlock) void k_resolve(const float* accum, int n_pixels, float inv_spp, uchar4* out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_pixels) return;
+    uchar4 px;
+    const float r = (inv_spp * accum[3 * i + 0]) * 255.99f, g = (inv_spp * accum[3 * i + 1]) * 255.99f, b = (inv_spp * accum[3 * i + 2]) * 255.99f;
+    px.x = (unsigned char)(r < 255.0f ? r : 255.0f);
+    px.y = (unsigned char)(g < 255.0f ? g : 255.0f);
+    px.z = (unsigned char)(b < 255.0f ? b : 255.0f);
+    px.w = 255;
+    out[i] = px;
+}
+
+__global__ __launch_bounds__(kBlock) void k_trace_probe(DScene S, Work Wk, const float* rays, uint32_t n, int any_hit,
+                                                        int* prim_out, float* t_out) {
+    __shared__ uint32_t s_stack[kLdsStackDepth * kBlock];
+    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t gstride = gridDim.x * kBlock;
+    const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride};
+    for (uint32_t i = gtid; i < n; i += gstride) {
+        const float* q = rays + (size_t)i * 8;
+        float t; int prim;
+        if (any_hit) {
+            const bool occ = traverse<true>(S, st, mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), q[6], q[7], &t, &prim);
+            prim_out[i] = occ ? 1 : 0;
+        } else {
+            traverse<false>(S, st, mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), q[6], 0.0f, &t, &prim);
+            prim_out[i] = prim;
+        }
+        t_out[i] = t;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_camera_probe(DCamera cam, int W, int H, uint32_t k0, uint32_t k1,
+                                                         const int* pixels, uint32_t n, float* out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int x = pixels[3 * i], j = pixels[3 * i + 1], s = pixels[3 * i + 2];
+    const RngKey key{k0, k1, (uint32_t)((H - 1 - j) * W + x), (uint32_t)s};
+    f3 o, d;
+    camera_ray(cam, W, H, x, j, key, &o, &d);
+    float* r = out + (size_t)i * 6;
+    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
+}
+
+}  // namespace
+
+// ============================================================================================
+// Host runtime
+// ============================================================================================
+struct rt_scene {
+    int device = 0;
+    DScene d{};
+    void* d_recs = nullptr; void* d_prims = nullptr; void* d_mats = nullptr; void* d_texs = nullptr; void* d_lights = nullptr;
+    std::vector<void*> d_tex_pixels;
+    rt_scene_info info{};
+    double ms_build = 0;
+    // camera inputs (NewCamera needs the aspect ratio, so the camera is finished per render)
+    rt_vec3 from, at, up; double aperture = 0, fov = 0;
+    // batch workspace, grown on demand
+    Work wk{}; int64_t wk_paths = 0; int wk_depth = 0; int wk_lpos = 0;
+    uint32_t* h_counters = nullptr;  // pinned
+    hipEvent_t ev[8] = {};
+    bool ev_ok = false;
+};
+
+namespace {
+
+void free_work(rt_scene* s) {
+    Work& w = s->wk;
+    void* ptrs[] = {w.ray_o, w.ray_d, w.thr, w.rad, w.queue[0], w.queue[1], w.phong_queue, w.vis, w.counters};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    uint32_t* ov = w.overflow; const uint32_t os = w.overflow_stride;
+    w = Work{};
+    w.overflow = ov; w.overflow_stride = os;
+    s->wk_paths = 0;
+}
+
+int ensure_work(rt_scene* s, int64_t paths, int depth, int lpos) {
+    if (paths <= s->wk_paths && depth <= s->wk_depth && lpos <= s->wk_lpos) return RT_OK;
+    free_work(s);
+    Work& w = s->wk;
+    HIP_TRY(hipMalloc((void**)&w.ray_o, paths * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&w.ray_d, paths * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&w.thr, paths * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&w.rad, paths * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&w.queue[0], paths * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&w.queue[1], paths * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&w.phong_queue, paths * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&w.vis, (size_t)paths * (size_t)(lpos > 0 ? lpos : 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&w.counters, (size_t)(2 * depth + 8) * sizeof(uint32_t)));
+    if (s->h_counters) { (void)hipHostFree(s->h_counters); s->h_counters = nullptr; }
+    HIP_TRY(hipHostMalloc((void**)&s->h_counters, (size_t)(2 * depth + 8) * sizeof(uint32_t)));
+    s->wk_paths = paths; s->wk_depth = depth; s->wk_lpos = lpos;
+    return RT_OK;
+}
+
+// NewCamera, camera.go:18-35, with the arguments GenerateImage passes (raytracer.go:59-68)
+DCamera make_camera(const rt_scene* s, int W, int H) {
+    const double fx = s->from.x - s->at.x, fy = s->from.y - s->at.y, fz = s->from.z - s->at.z;
+    const double focus = std::sqrt(fx * fx + fy * fy + fz * fz);
+    const double aspect = (double)W / (double)H;
+    const double theta = s->fov * M_PI / 180.0;
+    const double hh = std::tan(theta / 2), hw = aspect * hh;
+    auto unit = [](double v[3]) {
+        if (v[0] == 0 && v[1] == 0 && v[2] == 0) { v[0] = v[1] = v[2] = NAN; return; }
+        const double k = 1 / std::hypot(v[0], std::hypot(v[1], v[2]));
+        v[0] *= k; v[1] *= k; v[2] *= k;
+    };
+    double w[3] = {fx, fy, fz};
+    unit(w);
+    double u[3] = {s->up.y * w[2] - s->up.z * w[1], s->up.z * w[0] - s->up.x * w[2], s->up.x * w[1] - s->up.y * w[0]};
+    unit(u);
+    const double v[3] = {w[1] * u[2] - w[2] * u[1], w[2] * u[0] - w[0] * u[2], w[0] * u[1] - w[1] * u[0]};
+    const double from[3] = {s->from.x, s->from.y, s->from.z};
+    DCamera c;
+    for (int a = 0; a < 3; ++a) {
+        c.u[a] = (float)u[a]; c.v[a] = (float)v[a]; c.origin[a] = (float)from[a];
+        c.ll[a] = (float)(((from[a] - (hw * focus) * u[a]) - (hh * focus) * v[a]) - focus * w[a]);
+        c.hor[a] = (float)((2 * hw * focus) * u[a]);
+        c.ver[a] = (float)((2 * hh * focus) * v[a]);
+    }
+    c.lens = (float)(s->aperture / 2);
+    return c;
+}
+
+int validate_spec(const rt_image_spec* spec) {
+    if (!spec) return fail(RT_ERR_INVALID, "spec is NULL");
+    if (spec->bvh_traversal_algorithm != RT_BVH_DIJKSTRA && spec->bvh_traversal_algorithm != RT_BVH_DEPTH_FIRST_SEARCH)
+        return fail(RT_ERR_ALGORITHM, "No trace algorithm found for " + std::to_string(spec->bvh_traversal_algorithm));
+    if (spec->width <= 0 || spec->height <= 0) return fail(RT_ERR_INVALID, "width and height must be positive");
+    if ((int64_t)spec->width * spec->height > ((int64_t)1 << 31) - 1) return fail(RT_ERR_LIMIT, "image has more than 2^31-1 pixels");
+    if (spec->anti_aliasing_factor < 0 || spec->ray_tracing_max_depth < 0 || spec->soft_shadow_monte_carlo_repetitions < 0)
+        return fail(RT_ERR_INVALID, "negative AntiAliasingFactor / RayTracingMaxDepth / SoftShadowMonteCarloRepetitions");
+    if (spec->ray_tracing_max_depth > (1 << 20)) return fail(RT_ERR_LIMIT, "RayTracingMaxDepth > 2^20");
+    if (spec->soft_shadow_monte_carlo_repetitions > (1 << 16)) return fail(RT_ERR_LIMIT, "SoftShadowMonteCarloRepetitions > 65536");
+    return RT_OK;
+}
+
+inline int grid_for(unsigned long long n) {
+    unsigned long long b = (n + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    return (int)(b < (unsigned long long)kMaxGridBlocks ? b : (unsigned long long)kMaxGridBlocks);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+
+int rt_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(RT_ERR_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(RT_ERR_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RT_ERR_DEVICE, std::string("librtgo_hip is built for gfx950 only, found ") + prop.gcnArchName);
+    return RT_OK;
+}
+
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
+    if (!desc || !out) return fail(RT_ERR_INVALID, "desc/out is NULL");
+    *out = nullptr;
+    if (desc->n_shapes < 0 || desc->n_materials < 0 || desc->n_textures < 0 || desc->n_lights < 0)
+        return fail(RT_ERR_INVALID, "negative table size");
+    if (desc->n_shapes >= ((int64_t)1 << 28)) return fail(RT_ERR_LIMIT, "more than 2^28 shapes");
+    if (desc->n_materials >= ((int64_t)1 << 30)) return fail(RT_ERR_LIMIT, "more than 2^30 materials");
+    for (int64_t i = 0; i < desc->n_shapes; ++i) {
+        const rt_shape& s = desc->shapes[i];
+        if (s.kind != RT_SHAPE_SPHERE && s.kind != RT_SHAPE_TRIANGLE) return fail(RT_ERR_INVALID, "unknown shape kind");
+        if (s.material < 0 || s.material >= desc->n_materials) return fail(RT_ERR_INVALID, "shape material index out of range");
+    }
+    for (int64_t i = 0; i < desc->n_materials; ++i) {
+        const rt_material& m = desc->materials[i];
+        if (m.kind < RT_MAT_STANDARD || m.kind > RT_MAT_PHONGBLINN) return fail(RT_ERR_INVALID, "unknown material kind");
+        if (m.texture >= desc->n_textures) return fail(RT_ERR_INVALID, "material texture index out of range");
+    }
+    for (int64_t i = 0; i < desc->n_textures; ++i) {
+        const rt_texture& t = desc->textures[i];
+        if (t.kind != RT_TEX_CHECKERS && t.kind != RT_TEX_IMAGE) return fail(RT_ERR_INVALID, "unknown texture kind");
+        if (t.kind == RT_TEX_IMAGE && (!t.rgba || t.width <= 0 || t.height <= 0)) return fail(RT_ERR_INVALID, "image texture without pixels");
+    }
+    for (int64_t i = 0; i < desc->n_lights; ++i)
+        if (desc->lights[i].kind < RT_LIGHT_AMBIENT || desc->lights[i].kind > RT_LIGHT_SPOT) return fail(RT_ERR_INVALID, "unknown light kind");
+    int rc = rt_init(device);
+    if (rc != RT_OK) return rc;
+
+    const auto t0 = std::chrono::steady_clock::now();
+    FlatTree flat;
+    {
+        const std::vector<HostNode> nodes = build_octree(desc->shapes, desc->n_shapes);
+        const char* err = nullptr;
+        if (!flatten_octree(nodes, &flat, &err)) return fail(RT_ERR_LIMIT, err);
+    }
+    // shapes -> 3 float4 each, narrowed to fp32 (round to nearest)
+    std::vector<float> prims((size_t)desc->n_shapes * 12 + 12, 0.0f);
+    for (int64_t i = 0; i < desc->n_shapes; ++i) {
+        const rt_shape& s = desc->shapes[i];
+        float* p = prims.data() + (size_t)i * 12;
+        uint32_t bits = (uint32_t)s.material << 2;
+        if (s.kind == RT_SHAPE_TRIANGLE) {
+            bits |= kPrimTriangle | (s.single_sided ? kPrimSingleSided : 0u);
+            p[0] = (float)s.a.x; p[1] = (float)s.a.y; p[2] = (float)s.a.z;
+            p[3] = (float)s.b.x; p[4] = (float)s.b.y; p[5] = (float)s.b.z;
+            p[6] = (float)s.c.x; p[7] = (float)s.c.y; p[8] = (float)s.c.z;
+        } else {
+            p[0] = (float)s.a.x; p[1] = (float)s.a.y; p[2] = (float)s.a.z; p[3] = (float)s.b.x;
+        }
+        std::memcpy(&p[9], &bits, 4);
+    }
+    std::vector<DMaterial> mats((size_t)desc->n_materials + 1);
+    for (int64_t i = 0; i < desc->n_materials; ++i) {
+        const rt_material& m = desc->materials[i];
+        DMaterial& d = mats[(size_t)i];
+        d.kind = m.kind; d.texture = m.texture < 0 ? -1 : m.texture;
+        d.color[0] = (float)m.color.x; d.color[1] = (float)m.color.y; d.color[2] = (float)m.color.z;
+        d.spec[0] = (float)m.specular_color.x; d.spec[1] = (float)m.specular_color.y; d.spec[2] = (float)m.specular_color.z;
+        d.param = (float)m.param;
+    }
+
+    rt_scene* s = new rt_scene();
+    s->device = device;
+    s->from = desc->camera_look_from; s->at = desc->camera_look_at; s->up = desc->camera_up;
+    s->aperture = desc->camera_aperture; s->fov = desc->camera_fov_deg;
+    auto bail = [&](int code) { rt_scene_destroy(s); return code; };
+#define HIP_TRY_S(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_))); \
+    } while (0)
+
+    std::vector<DTexture> texs((size_t)desc->n_textures + 1);
+    int64_t tex_bytes = 0;
+    for (int64_t i = 0; i < desc->n_textures; ++i) {
+        const rt_texture& t = desc->textures[i];
+        DTexture& d = texs[(size_t)i];
+        d.kind = t.kind; d.w = t.width; d.h = t.height;
+        d.c1[0] = (float)t.color1.x; d.c1[1] = (float)t.color1.y; d.c1[2] = (float)t.color1.z;
+        d.c2[0] = (float)t.color2.x; d.c2[1] = (float)t.color2.y; d.c2[2] = (float)t.color2.z;
+        d.cw = (float)t.checkers_width; d.ch = (float)t.checkers_height;
+        d.rgba = nullptr;
+        if (t.kind == RT_TEX_IMAGE) {
+            const size_t n = (size_t)t.width * t.height * 4;
+            void* px = nullptr;
+            HIP_TRY_S(hipMalloc(&px, n));
+            s->d_tex_pixels.push_back(px);
+            HIP_TRY_S(hipMemcpy(px, t.rgba, n, hipMemcpyHostToDevice));
+            d.rgba = (const uint8_t*)px;
+            tex_bytes += (int64_t)n;
+        }
+    }
+    std::vector<DLight> lights((size_t)desc->n_lights + 1);
+    int n_pos = 0;
+    for (int64_t i = 0; i < desc->n_lights; ++i) {
+        const rt_light& l = desc->lights[i];
+        DLight& d = lights[(size_t)i];
+        d.kind = l.kind;
+        d.color[0] = (float)l.color.x; d.color[1] = (float)l.color.y; d.color[2] = (float)l.color.z;
+        d.pos[0] = (float)l.position.x; d.pos[1] = (float)l.position.y; d.pos[2] = (float)l.position.z;
+        double ld[3] = {l.look_at.x - l.position.x, l.look_at.y - l.position.y, l.look_at.z - l.position.z};
+        if (l.kind == RT_LIGHT_SPOT) {  // light.go:127: Unit(LookAt - Position)
+            if (ld[0] == 0 && ld[1] == 0 && ld[2] == 0) ld[0] = ld[1] = ld[2] = NAN;
+            else { const double k = 1 / std::hypot(ld[0], std::hypot(ld[1], ld[2])); ld[0] *= k; ld[1] *= k; ld[2] *= k; }
+        } else { ld[0] = ld[1] = ld[2] = 0; }
+        d.look_dir[0] = (float)ld[0]; d.look_dir[1] = (float)ld[1]; d.look_dir[2] = (float)ld[2];
+        d.intensity = (float)l.intensity; d.spec_intensity = (float)l.specular_intensity;
+        d.cos_angle = (float)std::cos(l.angle_deg * M_PI / 180.0);
+        d.decay = (float)l.decay;
+        if (l.kind != RT_LIGHT_AMBIENT) ++n_pos;
+    }
+
+    const size_t rec_bytes = (flat.records.size() + 1) * sizeof(ChildRecord);
+    HIP_TRY_S(hipMalloc(&s->d_recs, rec_bytes));
+    if (!flat.records.empty()) HIP_TRY_S(hipMemcpy(s->d_recs, flat.records.data(), flat.records.size() * sizeof(ChildRecord), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_prims, prims.size() * sizeof(float)));
+    HIP_TRY_S(hipMemcpy(s->d_prims, prims.data(), prims.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_mats, mats.size() * sizeof(DMaterial)));
+    HIP_TRY_S(hipMemcpy(s->d_mats, mats.data(), mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_texs, texs.size() * sizeof(DTexture)));
+    HIP_TRY_S(hipMemcpy(s->d_texs, texs.data(), texs.size() * sizeof(DTexture), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_lights, lights.size() * sizeof(DLight)));
+    HIP_TRY_S(hipMemcpy(s->d_lights, lights.data(), lights.size() * sizeof(DLight), hipMemcpyHostToDevice));
+
+    // traversal stack spill: worst case 7 pending siblings per level, beyond the LDS part
+    const int spill = flat.stack_bound > kLdsStackDepth ? flat.stack_bound - kLdsStackDepth : 0;
+    s->wk.overflow_stride = (uint32_t)kMaxGridBlocks * kBlock;
+    HIP_TRY_S(hipMalloc((void**)&s->wk.overflow, (size_t)(spill + 1) * s->wk.overflow_stride * sizeof(uint32_t)));
+
+    s->d.recs = (const float4*)s->d_recs; s->d.prims = (const float4*)s->d_prims;
+    s->d.materials = (const DMaterial*)s->d_mats; s->d.textures = (const DTexture*)s->d_texs;
+    s->d.lights = (const DLight*)s->d_lights;
+    s->d.n_lights = (int)desc->n_lights; s->d.n_pos_lights = n_pos; s->d.root_ref = flat.root_ref;
+    for (auto& e : s->ev) HIP_TRY_S(hipEventCreate(&e));
+    s->ev_ok = true;
+
+    s->info.n_shapes = desc->n_shapes; s->info.n_inner_nodes = flat.n_inner;
+    s->info.n_child_records = (int64_t)flat.records.size();
+    s->info.tree_depth = flat.depth; s->info.stack_bound = flat.stack_bound;
+    s->info.device_bytes = (int64_t)(rec_bytes + prims.size() * 4 + mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
+                                     lights.size() * sizeof(DLight) + (size_t)(spill + 1) * s->wk.overflow_stride * 4) + tex_bytes;
+    s->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out = s;
+    return RT_OK;
+#undef HIP_TRY_S
+}
+
+void rt_scene_destroy(rt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    free_work(s);
+    if (s->wk.overflow) (void)hipFree(s->wk.overflow);
+    if (s->h_counters) (void)hipHostFree(s->h_counters);
+    void* ptrs[] = {s->d_recs, s->d_prims, s->d_mats, s->d_texs, s->d_lights};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (void* p : s->d_tex_pixels) (void)hipFree(p);
+    if (s->ev_ok) for (auto& e : s->ev) (void)hipEventDestroy(e);
+    delete s;
+}
+
+int rt_scene_get_info(const rt_scene* s, rt_scene_info* out) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "scene/out is NULL");
+    *out = s->info;
+    return RT_OK;
+}
+
+int rt_render_accum_device(rt_scene* s, const rt_image_spec* spec, const rt_partition* part_in,
+                           float* d_accum, void* hip_stream, rt_stats* stats) {
+    if (!s || !d_accum) return fail(RT_ERR_INVALID, "scene/accum is NULL");
+    int rc = validate_spec(spec);
+    if (rc != RT_OK) return rc;
+    rt_partition part{};
+    part.seed = 0x5EED; part.mode = RT_PART_ALL; part.rank = 0; part.world_size = 1;
+    if (part_in) part = *part_in;
+    if (part.mode < RT_PART_ALL || part.mode > RT_PART_SAMPLES) return fail(RT_ERR_INVALID, "unknown partition mode");
+    if (part.mode == RT_PART_ALL) { part.rank = 0; part.world_size = 1; }
+    if (part.world_size < 1 || part.rank < 0 || part.rank >= part.world_size) return fail(RT_ERR_INVALID, "bad rank/world_size");
+    int tile = part.tile_size > 0 ? part.tile_size : 64;
+    if (tile % 8 != 0 || tile > 1024) return fail(RT_ERR_INVALID, "tile_size must be a multiple of 8, at most 1024");
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t stream = (hipStream_t)hip_stream;
+
+    const int W = spec->width, H = spec->height, D = spec->ray_tracing_max_depth;
+    const int spp = spec->anti_aliasing_factor, reps = spec->soft_shadow_monte_carlo_repetitions;
+    const int tiles_x = (W + tile - 1) / tile, tiles_y = (H + tile - 1) / tile;
+    const long long n_tiles = (long long)tiles_x * tiles_y;
+    const bool by_tiles = part.mode == RT_PART_TILES;
+    const long long my_tiles = by_tiles ? (n_tiles - part.rank + part.world_size - 1) / part.world_size : n_tiles;
+    int sA = 0, sB = spp;
+    if (part.mode == RT_PART_SAMPLES) {
+        sA = (int)((long long)spp * part.rank / part.world_size);
+        sB = (int)((long long)spp * (part.rank + 1) / part.world_size);
+    }
+    rt_stats st{};
+    st.ms_build = s->ms_build;
+    const long long n_local_pixels = my_tiles * tile * tile;
+    if (sB > sA && D > 0 && n_local_pixels > 0) {
+        int64_t max_paths = part.max_paths_per_batch > 0 ? part.max_paths_per_batch : kDefaultMaxPaths;
+        if (max_paths < (int64_t)tile * tile) max_paths = (int64_t)tile * tile;
+        if (max_paths > ((int64_t)1 << 30)) max_paths = (int64_t)1 << 30;
+        const int ns_max = (int)std::min<long long>(sB - sA, std::min<long long>(64, max_paths / ((long long)tile * tile)));
+        const long long pix_per_batch = std::max<long long>(1, max_paths / ns_max / ((long long)tile * tile)) * tile * tile;
+        rc = ensure_work(s, (int64_t)std::min<long long>(pix_per_batch, n_local_pixels) * ns_max, D, s->d.n_pos_lights);
+        if (rc != RT_OK) return rc;
+        Work& wk = s->wk;
+        // lanes per (hit, light) in the shadow kernel: smallest power of two >= min(reps, 64)
+        int group = 1, group_shift = 0;
+        while (group < reps && group < 64) { group <<= 1; ++group_shift; }
+
+        const bool timed = stats != nullptr;
+        hipEvent_t* ev = s->ev;
+        if (timed) HIP_TRY(hipEventRecord(ev[6], stream));
+        bool pend_shadow = false;
+        auto harvest_shadow = [&]() {
+            if (!pend_shadow) return;
+            float a = 0, b = 0;
+            (void)hipEventElapsedTime(&a, ev[3], ev[4]);
+            (void)hipEventElapsedTime(&b, ev[4], ev[5]);
+            st.ms_shadow += a; st.ms_shade += b;
+            pend_shadow = false;
+        };
+        const size_t n_ctr = (size_t)(2 * D + 8);
+        for (int s0 = sA; s0 < sB; s0 += ns_max) {
+            const int ns = std::min(ns_max, sB - s0);
+            for (long long lp0 = 0; lp0 < n_local_pixels; lp0 += pix_per_batch) {
+                Batch B{};
+                B.W = W; B.H = H; B.tile = tile; B.tiles_x = tiles_x;
+                B.rank = part.rank; B.world = part.world_size; B.by_tiles = by_tiles ? 1 : 0;
+                B.lp0 = lp0; B.npix = (int)std::min<long long>(pix_per_batch, n_local_pixels - lp0);
+                B.ns = ns; B.s0 = s0; B.max_depth = D; B.reps = reps;
+                B.k0 = (uint32_t)part.seed; B.k1 = (uint32_t)(part.seed >> 32);
+                const long long slots = (long long)B.npix * ns;
+                const DCamera cam = make_camera(s, W, H);
+                HIP_TRY(hipMemsetAsync(wk.counters, 0, n_ctr * sizeof(uint32_t), stream));
+                hipLaunchKernelGGL(k_raygen, dim3((unsigned)((slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, B, cam, wk);
+                HIP_TRY(hipMemcpyAsync(s->h_counters, wk.counters, n_ctr * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                harvest_shadow();
+                uint32_t nq = s->h_counters[0];
+                st.paths += nq;
+                for (int b = 0; b < D && nq > 0; ++b) {
+                    uint32_t* q = wk.queue[b & 1];
+                    uint32_t* qn = wk.queue[(b + 1) & 1];
+                    if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
+                    hipLaunchKernelGGL(k_extend, dim3(grid_for(nq)), dim3(kBlock), 0, stream, s->d, wk, q, nq);
+                    if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
+                    hipLaunchKernelGGL(k_shade, dim3((nq + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, B, wk, q, nq, qn, b);
+                    if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
+                    HIP_TRY(hipMemcpyAsync(s->h_counters, wk.counters, n_ctr * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    harvest_shadow();
+                    if (timed) {
+                        float a = 0, c = 0;
+                        (void)hipEventElapsedTime(&a, ev[0], ev[1]);
+                        (void)hipEventElapsedTime(&c, ev[1], ev[2]);
+                        st.ms_extend += a; st.ms_shade += c;
+                    }
+                    if (b == 0) st.rays_primary += nq; else st.rays_continuation += nq;
+                    const uint32_t np = s->h_counters[D + 1 + b];
+                    nq = s->h_counters[b + 1];
+                    if (np > 0) {
+                        st.phong_hits += np;
+                        st.rays_shadow_reference_equivalent += (uint64_t)np * s->d.n_pos_lights * reps;
+                        if (timed) HIP_TRY(hipEventRecord(ev[3], stream));
+                        if (s->d.n_pos_lights > 0 && reps > 0) {
+                            const unsigned long long lanes = (unsigned long long)np * s->d.n_pos_lights * group;
+                            hipLaunchKernelGGL(k_shadow, dim3(grid_for(lanes)), dim3(kBlock), 0, stream, s->d, B, wk, np, b, group, group_shift);
+                        } else if (s->d.n_pos_lights > 0) {
+                            HIP_TRY(hipMemsetAsync(wk.vis, 0, (size_t)np * s->d.n_pos_lights * sizeof(uint32_t), stream));
+                        }
+                        if (timed) HIP_TRY(hipEventRecord(ev[4], stream));
+                        hipLaunchKernelGGL(k_phong, dim3((np + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, B, wk, np);
+                        if (timed) { HIP_TRY(hipEventRecord(ev[5], stream)); pend_shadow = true; }
+                    }
+                }
+                hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((B.npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, B, wk, d_accum);
+                // shadow-ray counter of this batch (u64 at counters[2D+2])
+                HIP_TRY(hipMemcpyAsync(s->h_counters, wk.counters, n_ctr * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                harvest_shadow();
+                unsigned long long sh = 0;
+                std::memcpy(&sh, s->h_counters + 2 * D + 2, 8);
+                st.rays_shadow += sh;
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        if (timed) {
+            HIP_TRY(hipEventRecord(ev[7], stream));
+            HIP_TRY(hipEventSynchronize(ev[7]));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[6], ev[7]));
+            st.ms_render = ms;
+        }
+    }
+    if (stats) *stats = st;
+    return RT_OK;
+}
+
+int rt_resolve_device(const float* d_accum, int32_t width, int32_t height, int32_t spp, uint8_t* d_rgba, void* hip_stream) {
+    if (!d_accum || !d_rgba || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "bad resolve arguments");
+    const int n = width * height;
+    // AntiAliasingFactor 0: the reference scales by 1/0 = +Inf and 0 * Inf = NaN -> uint8(NaN); we emit 0
+    const float inv = spp > 0 ? 1.0f / (float)spp : 0.0f;
+    hipLaunchKernelGGL(k_resolve, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)hip_stream, d_accum, n, inv, (uchar4*)d_rgba);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_render_accum(rt_scene* s, const rt_image_spec* spec, const rt_partition* part, float* accum_out, rt_stats* stats) {
+    if (!s || !accum_out) return fail(RT_ERR_INVALID, "scene/accum is NULL");
+    int rc = validate_spec(spec);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t bytes = (size_t)spec->width * spec->height * 3 * sizeof(float);
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, bytes));
+    hipError_t e = hipMemset(d, 0, bytes);
+    rc = e == hipSuccess ? rt_render_accum_device(s, spec, part, d, nullptr, stats) : fail(RT_ERR_DEVICE, hipGetErrorString(e));
+    if (rc == RT_OK) {
+        e = hipMemcpy(accum_out, d, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+int rt_render(rt_scene* s, const rt_image_spec* spec, const rt_partition* part, uint8_t* rgba_out, rt_stats* stats) {
+    if (!s || !rgba_out) return fail(RT_ERR_INVALID, "scene/rgba_out is NULL");
+    int rc = validate_spec(spec);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t npx = (size_t)spec->width * spec->height;
+    float* d = nullptr;
+    uint8_t* d8 = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, npx * 3 * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&d8, npx * 4);
+    if (e != hipSuccess) { (void)hipFree(d); return fail(RT_ERR_DEVICE, hipGetErrorString(e)); }
+    e = hipMemset(d, 0, npx * 3 * sizeof(float));
+    rc = e == hipSuccess ? rt_render_accum_device(s, spec, part, d, nullptr, stats) : fail(RT_ERR_DEVICE, hipGetErrorString(e));
+    if (rc == RT_OK) rc = rt_resolve_device(d, spec->width, spec->height, spec->anti_aliasing_factor, d8, nullptr);
+    if (rc == RT_OK) {
+        e = hipMemcpy(rgba_out, d8, npx * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    (void)hipFree(d8);
+    return rc;
+}
+
+int rt_generate_image(const rt_scene_desc* desc, const rt_image_spec* spec, const rt_partition* part, uint8_t* rgba_out, rt_stats* stats) {
+    int rc = validate_spec(spec);
+    if (rc != RT_OK) return rc;
+    rt_scene* s = nullptr;
+    rc = rt_scene_create(desc, 0, &s);
+    if (rc != RT_OK) return rc;
+    rc = rt_render(s, spec, part, rgba_out, stats);
+    rt_scene_destroy(s);
+    return rc;
+}
+
+int rt_trace_rays(rt_scene* s, const float* rays, int64_t n, int32_t any_hit, int32_t* prim_out, float* t_out) {
+    if (!s || !rays || !prim_out || !t_out || n < 0) return fail(RT_ERR_INVALID, "bad trace arguments");
+    if (n == 0) return RT_OK;
+    if (n > ((int64_t)1 << 30)) return fail(RT_ERR_LIMIT, "more than 2^30 rays in one call");
+    HIP_TRY(hipSetDevice(s->device));
+    float* d_rays = nullptr; int* d_prim = nullptr; float* d_t = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_rays, (size_t)n * 8 * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&d_prim, (size_t)n * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_t, (size_t)n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_trace_probe, dim3(grid_for((unsigned long long)n)), dim3(kBlock), 0, nullptr, s->d, s->wk, d_rays, (uint32_t)n, any_hit, d_prim, d_t);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(prim_out, d_prim, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(t_out, d_t, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_rays); (void)hipFree(d_prim); (void)hipFree(d_t);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_camera_rays(rt_scene* s, const rt_image_spec* spec, uint64_t seed, const int32_t* pixels, int64_t n, float* rays_out) {
+    if (!s || !pixels || !rays_out || n < 0) return fail(RT_ERR_INVALID, "bad camera arguments");
+    int rc = validate_spec(spec);
+    if (rc != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    int* d_px = nullptr; float* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_px, (size_t)n * 3 * sizeof(int)));
+    hipError_t e = hipMalloc((void**)&d_out, (size_t)n * 6 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_px, pixels, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const DCamera cam = make_camera(s, spec->width, spec->height);
+        hipLaunchKernelGGL(k_camera_probe, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, cam, spec->width, spec->height,
+                           (uint32_t)seed, (uint32_t)(seed >> 32), d_px, (uint32_t)n, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(rays_out, d_out, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_px); (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(RT_ERR_DEVICE, hipGetErrorString(e));
+    return RT_OK;
+}
+
+}  // extern "C"
