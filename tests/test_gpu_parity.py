@@ -1,0 +1,330 @@
+"""Parity of the HIP path (through the C-ABI, librtgo_hip.so) against the CPU oracle.
+
+Bars:  bit-exact for camera rays, primitive IDs and hit t against the oracle's float32 mode (same
+operation order); primitive IDs against the float64 / best-first mode (the reference's own
+arithmetic) may differ only on silhouette rays — rate reported and bounded; accumulated radiance
+within 1e-3 absolute of the float32 oracle on >= 99.9 % of pixels (device atan2f/acosf/powf differ
+from glibc's by ulps and can flip a texel or a Schlick decision); the reference's own image gate
+(20/255 per channel, < 1 % of pixels) against the golden PNG.
+"""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import compare_images
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev_c1(backend, c1):
+    spec, scene = c1
+    backend.init(0)
+    d = backend.DeviceScene(scene)
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope="module")
+def orc_c1(bridge, c1):
+    o = bridge.OracleScene(c1[1])
+    yield o
+    o.close()
+
+
+def _mesh_scene(rt, scenes, level=4):
+    V = rt.Vec
+    mesh = rt.TriangleMesh(scenes._fit(scenes.icosphere_mesh(level, seed=5), (0, 0, 0), 3.0), False,
+                           rt.PhongBlinn(ColorFrac=V(0.8, 0.7, 0.6), SpecularColorFrac=V(1, 1, 1), SpecHardness=12))
+    shapes = [rt.TrianglePlane(V(-30, 0, -30), V(-30, 0, 30), V(30, 0, -30), False, rt.Metal(Albedo=V(0.9, 0.9, 0.9), Fuzz=0.05)),
+              rt.TrianglePlane(V(30, 0, 30), V(30, 0, -30), V(-30, 0, 30), False, rt.Metal(Albedo=V(0.9, 0.9, 0.9), Fuzz=0.05)),
+              rt.Sphere(V(2.6, 1.0, -1.0), 1.0, rt.Dielectric(RefractiveIndex=1.52)),
+              rt.Sphere(V(-2.6, 1.0, -1.0), 1.0, rt.Metal(Albedo=V(1, 0.8, 0.6), Fuzz=0.2)),
+              rt.Sphere(V(0.0, 0.5, -2.5), 0.5, rt.Standard(Texture=rt.CheckersTexture(V(1, 0, 0), V(1, 1, 0), 8, 8))),
+              mesh]
+    lights = [rt.AmbientLight(V(1, 1, 1), 0.1),
+              rt.PointLight(ColorFrac=V(1, 0.9, 0.8), Position=V(4, 8, -5), LightIntensity=80, SpecularLightIntensity=30,
+                            InverseSquareLawDecayFactor=0.7),
+              rt.SpotLight(ColorFrac=V(0.6, 0.7, 1.0), Position=V(-5, 7, -4), LightIntensity=90, SpecularLightIntensity=30,
+                           LookAt=V(0, 1, 0), Angle=25, InverseSquareLawDecayFactor=0.7)]
+    spec = rt.ImageSpec(192, 108, 4, 8, 5, 1, 0)
+    scene = rt.Scene(V(0, 3, -8), V(0, 1.5, 0), V(0, 1, 0), V(0, 0, 0), 0.08, 50.0, shapes, lights)
+    return spec, scene
+
+
+def _rand_pixels(spec, n, seed):
+    rng = np.random.default_rng(seed)
+    return np.stack([rng.integers(0, spec.Width, n), rng.integers(0, spec.Height, n),
+                     rng.integers(0, max(1, spec.AntiAliasingFactor), n)], 1).astype(np.int32)
+
+
+def test_camera_rays_bit_exact(dev_c1, orc_c1, c1, bridge):
+    spec = c1[0]
+    px = _rand_pixels(spec, 50000, 1)
+    g = dev_c1.camera_rays(spec, px)
+    o = orc_c1.camera_rays(spec, px, mode=bridge.F32_STACK).astype(np.float32)
+    assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
+    o64 = orc_c1.camera_rays(spec, px, mode=bridge.F64_DIJKSTRA)
+    assert np.abs(g - o64).max() < 2e-6
+
+
+def test_primary_hit_ids_bit_exact_c1(dev_c1, orc_c1, c1, bridge):
+    spec = c1[0]
+    # deterministic pixel-centre-free check: every pixel of the 640x380 frame, sample 0
+    xs, ys = np.meshgrid(np.arange(spec.Width), np.arange(spec.Height))
+    px = np.stack([xs.ravel(), ys.ravel(), np.zeros(xs.size, int)], 1).astype(np.int32)
+    rays = np.zeros((px.shape[0], 8), np.float32)
+    rays[:, :6] = dev_c1.camera_rays(spec, px)
+    gp, gt = dev_c1.trace_rays(rays)
+    op, ot = orc_c1.trace_rays(rays.astype(np.float64), mode=bridge.F32_STACK)
+    assert np.array_equal(gp, op)
+    hit = op >= 0
+    assert np.array_equal(gt[hit].view(np.uint32), ot[hit].astype(np.float32).view(np.uint32))
+    p64, _ = orc_c1.trace_rays(rays.astype(np.float64), mode=bridge.F64_DIJKSTRA)
+    mism = int((gp != p64).sum())
+    print(f"C1 primary IDs vs float64 best-first: {mism} / {gp.size} differ")
+    assert mism <= gp.size * 1e-4
+    assert set(np.unique(gp)) <= set(range(-1, 11))
+
+
+def test_secondary_and_shadow_rays_bit_exact(backend, bridge, rt, scenes):
+    """Mirror-bounce secondary rays (non-unit directions, origins on surfaces) and any-hit shadow rays
+    on a 5k-triangle mesh scene."""
+    spec, scene = _mesh_scene(rt, scenes)
+    with backend.DeviceScene(scene) as dev, bridge.OracleScene(scene) as osc:
+        px = _rand_pixels(spec, 30000, 2)
+        rays = np.zeros((px.shape[0], 8), np.float32)
+        rays[:, :6] = dev.camera_rays(spec, px)
+        gp, gt = dev.trace_rays(rays)
+        op, ot = osc.trace_rays(rays.astype(np.float64), mode=bridge.F32_STACK)
+        assert np.array_equal(gp, op)
+        hit = gp >= 0
+        assert np.array_equal(gt[hit], ot[hit].astype(np.float32))
+        # secondary rays leaving the hit points in fuzzed mirror-ish directions, not normalised
+        rng = np.random.default_rng(9)
+        o = rays[hit, :3] + gt[hit, None] * rays[hit, 3:6]
+        d = rays[hit, 3:6] * np.array([1, -1, 1], np.float32) + 0.3 * rng.normal(size=(hit.sum(), 3)).astype(np.float32)
+        sec = np.zeros((o.shape[0], 8), np.float32)
+        sec[:, :3], sec[:, 3:6] = o, d
+        gp2, gt2 = dev.trace_rays(sec)
+        op2, ot2 = osc.trace_rays(sec.astype(np.float64), mode=bridge.F32_STACK)
+        assert np.array_equal(gp2, op2)
+        h2 = gp2 >= 0
+        assert np.array_equal(gt2[h2], ot2[h2].astype(np.float32))
+        p64, _ = osc.trace_rays(sec.astype(np.float64), mode=bridge.F64_DIJKSTRA)
+        print(f"secondary IDs vs float64 best-first: {(gp2 != p64).sum()} / {gp2.size} differ")
+        assert (gp2 != p64).mean() < 2e-3
+        # shadow rays towards a light: any-hit, tMin 0.01, tMax = distance
+        L = np.array([4, 8, -5], np.float32)
+        v = L - o
+        dist = np.sqrt((v * v).sum(1)).astype(np.float32)
+        sh = np.zeros((o.shape[0], 8), np.float32)
+        sh[:, :3], sh[:, 3:6], sh[:, 6], sh[:, 7] = o, v / dist[:, None], 0.01, dist
+        ga, _ = dev.trace_rays(sh, any_hit=True)
+        oa, _ = osc.trace_rays(sh.astype(np.float64), mode=bridge.F32_STACK, any_hit=True)
+        assert np.array_equal(ga, oa) and 0 < ga.mean() < 1
+
+
+def test_accumulation_matches_oracle(dev_c1, orc_c1, c1, bridge):
+    spec = copy.copy(c1[0])
+    spec.AntiAliasingFactor = 4
+    acc, st = dev_c1.render_accum(spec)
+    ref, _, ctr = orc_c1.render(spec, mode=bridge.F32_STACK, rgba=False)
+    assert st.rays_primary == ctr["rays_primary"] == 640 * 380 * 4
+    assert st.rays_continuation == ctr["rays_continuation"]
+    assert st.phong_hits == ctr["phong_hits"]
+    assert st.rays_shadow == ctr["rays_shadow"]
+    assert st.rays_shadow_reference_equivalent == st.phong_hits * 2 * spec.SoftShadowMonteCarloRepetitions
+    d = np.abs(acc.astype(np.float64) - ref).max(-1)
+    assert (d > 1e-3).mean() <= 1e-3, f"{(d > 1e-3).sum()} pixels off, max {d.max()}"
+    ref64, _, _ = orc_c1.render(spec, mode=bridge.F64_DIJKSTRA, rgba=False)
+    d64 = np.abs(acc.astype(np.float64) - ref64).max(-1) / spec.AntiAliasingFactor
+    print(f"vs float64 oracle: mean |d| {d64.mean():.2e}, pixels > 1/255: {(d64 > 1 / 255).sum()}")
+    assert (d64 > 1 / 255).mean() < 5e-3
+
+
+def test_mesh_scene_accumulation_matches_oracle(backend, bridge, rt, scenes):
+    spec, scene = _mesh_scene(rt, scenes)
+    with backend.DeviceScene(scene) as dev, bridge.OracleScene(scene) as osc:
+        acc, st = dev.render_accum(spec)
+        ref, _, ctr = osc.render(spec, mode=bridge.F32_STACK, rgba=False)
+    assert st.rays_primary == ctr["rays_primary"] and st.rays_continuation == ctr["rays_continuation"]
+    assert st.rays_shadow == ctr["rays_shadow"] and st.phong_hits == ctr["phong_hits"]
+    d = np.abs(acc.astype(np.float64) - ref).max(-1)
+    assert (d > 1e-3).mean() <= 2e-3, f"{(d > 1e-3).sum()} pixels off, max {d.max()}"
+
+
+def test_reference_regression_gate(dev_c1, c1, golden_rgba):
+    """TestRegression (raytracer_test.go:12-30): both algorithm ids, compared with the golden image and
+    with each other under compareImages' tolerance."""
+    spec = copy.copy(c1[0])
+    spec.BvhTraversalAlgorithm = 1  # DepthFirstSearch
+    img_dfs, _ = dev_c1.render(spec)
+    spec.BvhTraversalAlgorithm = 0  # Dijkstra
+    img_dij, st = dev_c1.render(spec)
+    for a, b in ((img_dij, golden_rgba), (img_dfs, golden_rgba), (img_dij, img_dfs)):
+        different, allowed = compare_images(a, b)
+        assert different < allowed, (different, allowed)
+    for colour, count in (((0, 0, 0), 62209), ((51, 0, 0), 34104), ((150, 111, 51), 16572)):
+        gm = (golden_rgba[..., :3] == colour).all(-1)
+        assert ((img_dij[..., :3] == colour).all(-1) & gm).sum() >= 0.97 * count
+    assert (img_dij[..., 3] == 255).all()
+    assert st.rays_primary == 640 * 380 * 32
+
+
+def test_render_is_deterministic_and_seeded(dev_c1, c1):
+    spec = copy.copy(c1[0])
+    spec.AntiAliasingFactor = 2
+    a, _ = dev_c1.render_accum(spec, seed=7)
+    b, _ = dev_c1.render_accum(spec, seed=7)
+    c, _ = dev_c1.render_accum(spec, seed=8)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+def test_partitions_reassemble_the_frame(dev_c1, c1, rt):
+    """Tile split: the per-rank buffers are disjoint and sum to the single-GPU frame bit-exactly.
+    Sample split: same samples, different fp32 summation order.  Also batches smaller than the frame."""
+    abi = rt._abi
+    spec = copy.copy(c1[0])
+    spec.Width, spec.Height, spec.AntiAliasingFactor = 200, 120, 6  # not a multiple of the tile size
+    full, st = dev_c1.render_accum(spec, seed=3)
+    small, _ = dev_c1.render_accum(spec, part=abi.partition(seed=3, max_paths=64 * 64 * 2))
+    assert np.array_equal(full, small)
+    parts = [dev_c1.render_accum(spec, part=abi.partition(seed=3, mode=abi.RT_PART_TILES, rank=r, world_size=3, tile_size=32))
+             for r in range(3)]
+    owned = [(p[0] != 0).any(-1) for p in parts]
+    assert not (owned[0] & owned[1]).any() and not (owned[1] & owned[2]).any()
+    assert np.array_equal(parts[0][0] + parts[1][0] + parts[2][0], full)
+    assert sum(p[1].paths for p in parts) == st.paths == 200 * 120 * 6
+    sp = [dev_c1.render_accum(spec, part=abi.partition(seed=3, mode=abi.RT_PART_SAMPLES, rank=r, world_size=4)) for r in range(4)]
+    assert sum(p[1].paths for p in sp) == st.paths
+    assert np.abs(sum(p[0].astype(np.float64) for p in sp) - full).max() < 1e-5
+
+
+def test_error_behaviour(backend, dev_c1, c1, rt):
+    spec = copy.copy(c1[0])
+    spec.BvhTraversalAlgorithm = 2  # the reference panics: "No trace algorithm found for 2"
+    with pytest.raises(backend.RtgoError) as e:
+        dev_c1.render(spec)
+    assert e.value.code == rt._abi.RT_ERR_ALGORITHM and "No trace algorithm found for 2" in str(e.value)
+    spec = copy.copy(c1[0])
+    spec.Width = 0
+    with pytest.raises(backend.RtgoError):
+        dev_c1.render(spec)
+    bad = rt.Scene(Shapes=[rt.Sphere(rt.Vec(0, 0, 0), 1.0, object())])
+    with pytest.raises(TypeError):
+        backend.DeviceScene(bad)
+
+
+def test_edge_cases(backend, bridge, rt):
+    V = rt.Vec
+    cam = dict(CameraLookFrom=V(0, 1, -6), CameraLookAt=V(0, 1, 0), CameraUp=V(0, 1, 0), CameraFov=50.0)
+    spec = rt.ImageSpec(40, 24, 3, 4, 2, 1, 0)
+    # empty scene: every pixel is background
+    with backend.DeviceScene(rt.Scene(Shapes=[], Lights=[], **cam)) as dev:
+        pix, st = dev.render(spec)
+        assert (pix[..., :3] == 0).all() and (pix[..., 3] == 255).all() and st.rays_primary == 40 * 24 * 3
+    # one shape, no lights: PhongBlinn is black, Standard is its colour
+    one = rt.Scene(Shapes=[rt.Sphere(V(0, 1, 0), 1.0, rt.Standard(ColorFrac=V(0.5, 0.25, 1.0)))], Lights=[], **cam)
+    with backend.DeviceScene(one) as dev, bridge.OracleScene(one) as osc:
+        pix, st = dev.render(spec)
+        ref = osc.render(spec, mode=bridge.F32_STACK)[1]
+        assert np.array_equal(pix, ref) and tuple(pix[12, 20, :3]) == (127, 63, 255)
+        # depth 0: color() returns background for every hit (raytracer.go:145); spp 0 handled
+        s0 = copy.copy(spec); s0.RayTracingMaxDepth = 0
+        assert (dev.render(s0)[0][..., :3] == 0).all()
+    # reps 0 and ambient-only lighting; spot light that sees nothing
+    lit = rt.Scene(Shapes=[rt.Sphere(V(0, 1, 0), 1.0, rt.PhongBlinn(ColorFrac=V(1, 1, 1), SpecularColorFrac=V(1, 1, 1), SpecHardness=2))],
+                   Lights=[rt.AmbientLight(V(0, 1, 0), 0.5),
+                           rt.SpotLight(ColorFrac=V(1, 1, 1), Position=V(0, 9, 0), LightIntensity=50, SpecularLightIntensity=5,
+                                        LookAt=V(0, 20, 0), Angle=10, InverseSquareLawDecayFactor=1)], **cam)
+    with backend.DeviceScene(lit) as dev, bridge.OracleScene(lit) as osc:
+        for reps in (0, 1, 3, 70):  # 70 > 64 lanes: several repetitions per lane
+            s = copy.copy(spec); s.SoftShadowMonteCarloRepetitions = reps
+            acc, st = dev.render_accum(s)
+            ref, _, ctr = osc.render(s, mode=bridge.F32_STACK, rgba=False)
+            assert st.rays_shadow == ctr["rays_shadow"] == 0  # the cone never contains the sphere
+            assert np.abs(acc - ref).max() < 1e-5
+            assert tuple(dev.render(s)[0][12, 20, :3]) == (0, 127, 0)
+
+
+def test_soft_shadow_repetition_counts(backend, bridge, rt):
+    """Repetition counts that are not powers of two and > 64 exercise the lane-group ballot count."""
+    V = rt.Vec
+    scene = rt.Scene(CameraLookFrom=V(0, 4, -8), CameraLookAt=V(0, 0.5, 0), CameraUp=V(0, 1, 0), CameraFov=45.0,
+                     Shapes=[rt.TrianglePlane(V(-20, 0, -20), V(-20, 0, 20), V(20, 0, -20), False,
+                                              rt.PhongBlinn(ColorFrac=V(0.9, 0.9, 0.9), SpecularColorFrac=V(0.2, 0.2, 0.2), SpecHardness=4)),
+                             rt.Sphere(V(0, 1.0, 0), 1.0, rt.PhongBlinn(ColorFrac=V(0.9, 0.3, 0.3), SpecularColorFrac=V(1, 1, 1), SpecHardness=16))],
+                     Lights=[rt.PointLight(ColorFrac=V(1, 1, 1), Position=V(2, 3.0, -1), LightIntensity=8, SpecularLightIntensity=4,
+                                           InverseSquareLawDecayFactor=1),
+                             rt.PointLight(ColorFrac=V(0.3, 0.5, 1), Position=V(-3, 2.5, -2), LightIntensity=6, SpecularLightIntensity=2,
+                                           InverseSquareLawDecayFactor=1)])
+    with backend.DeviceScene(scene) as dev, bridge.OracleScene(scene) as osc:
+        for reps in (1, 3, 16, 33, 64, 100):
+            spec = rt.ImageSpec(64, 40, 2, 4, reps, 1, 0)
+            acc, st = dev.render_accum(spec)
+            ref, _, ctr = osc.render(spec, mode=bridge.F32_STACK, rgba=False)
+            assert st.rays_shadow == ctr["rays_shadow"] == st.phong_hits * 2 * reps
+            d = np.abs(acc.astype(np.float64) - ref).max()
+            assert d < 1e-4, (reps, d)
+
+
+def test_deep_tree_uses_stack_spill(backend, bridge, rt):
+    """Nearly coincident centroids make the octree recurse until the 1e-10 jitter separates them
+    (accelerationstructures.go:265-279); single-child chains are dropped by the flattener and the
+    traversal stack may exceed its LDS part.  Results still match the oracle bit for bit."""
+    V = rt.Vec
+    rng = np.random.default_rng(4)
+    shapes = []
+    mat = rt.Standard(ColorFrac=V(1, 1, 1))
+    for k in range(300):  # clusters of tiny offsets around a few centres -> deep, unbalanced tree
+        c = np.array([(k % 5) - 2.0, 1.0, (k % 3) * 0.5]) + rng.normal(size=3) * 10.0 ** -(1 + k % 9)
+        shapes.append(rt.Sphere(V(*c), 0.3, mat))
+    scene = rt.Scene(CameraLookFrom=V(0, 1, -7), CameraLookAt=V(0, 1, 0), CameraUp=V(0, 1, 0), CameraFov=60.0, Shapes=shapes, Lights=[])
+    spec = rt.ImageSpec(96, 54, 1, 2, 1, 1, 0)
+    with backend.DeviceScene(scene) as dev, bridge.OracleScene(scene) as osc:
+        info = dev.info()
+        print("deep tree:", info, osc.tree_info())
+        assert info["tree_depth"] < osc.tree_info()["max_depth"]
+        px = _rand_pixels(spec, 5184, 6)
+        rays = np.zeros((px.shape[0], 8), np.float32)
+        rays[:, :6] = dev.camera_rays(spec, px)
+        gp, gt = dev.trace_rays(rays)
+        op, ot = osc.trace_rays(rays.astype(np.float64), mode=bridge.F32_STACK)
+        assert np.array_equal(gp, op) and np.array_equal(gt[gp >= 0], ot[gp >= 0].astype(np.float32))
+        p64, _ = osc.trace_rays(rays.astype(np.float64), mode=bridge.F64_DIJKSTRA)
+        assert (gp != p64).mean() < 5e-3
+
+
+def test_large_mesh_properties(backend, bridge, rt, scenes):
+    """Size-independent properties on a 328k-triangle stand-in at a size the oracle cannot render in
+    seconds: IDs match the oracle on a ray sample; a ray aimed at a triangle's centroid from outside
+    hits at t no farther than that triangle; any-hit agrees with closest-hit."""
+    spec, scene = scenes.config3(320, 180, 2, 4, nu=405, nv=405)
+    with backend.DeviceScene(scene) as dev, bridge.OracleScene(scene) as osc:
+        assert dev.info()["n_shapes"] == 10 + 2 * 405 * 405
+        px = _rand_pixels(spec, 20000, 8)
+        rays = np.zeros((px.shape[0], 8), np.float32)
+        rays[:, :6] = dev.camera_rays(spec, px)
+        gp, gt = dev.trace_rays(rays)
+        op, ot = osc.trace_rays(rays.astype(np.float64), mode=bridge.F32_STACK)
+        assert np.array_equal(gp, op) and np.array_equal(gt, ot.astype(np.float32))
+        assert (gp >= 0).all()  # closed room + camera inside... the open front is behind the camera
+        mesh = scene.Shapes[-1].vertices
+        rng = np.random.default_rng(10)
+        pick = rng.integers(0, mesh.shape[0], 5000)
+        target = mesh[pick].mean(1)
+        origin = np.array([0.0, 4.0, -9.0])
+        d = target - origin
+        dist = np.linalg.norm(d, axis=1)
+        r = np.zeros((5000, 8), np.float32)
+        r[:, :3], r[:, 3:6] = origin, d / dist[:, None]
+        p, t = dev.trace_rays(r)
+        assert (p >= 0).all() and (t <= dist * (1 + 1e-4)).all()
+        r[:, 6], r[:, 7] = 0.01, t * (1 + 1e-3)
+        occ, _ = dev.trace_rays(r, any_hit=True)
+        assert occ.all()
+        r[:, 7] = t * (1 - 1e-3)
+        occ, _ = dev.trace_rays(r, any_hit=True)
+        assert not occ.any()

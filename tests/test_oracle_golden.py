@@ -1,0 +1,122 @@
+"""Pins the CPU oracle to the reference's own regression artefact (the only fixture the
+reference holds for this path): samples_images/code_example.png with the tolerance of
+raytracer_test.go:32-80, and the flat-colour known answers of that image."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import compare_images
+
+
+@pytest.fixture(scope="module")
+def oracle_c1(bridge, c1):
+    spec, scene = c1
+    osc = bridge.OracleScene(scene)
+    acc, pix, ctr = osc.render(spec, mode=bridge.F64_DIJKSTRA)
+    return osc, spec, acc, pix, ctr
+
+
+def test_oracle_matches_reference_golden(oracle_c1, golden_rgba):
+    _, _, _, pix, _ = oracle_c1
+    different, allowed = compare_images(pix, golden_rgba)
+    assert different < allowed, f"{different} pixels differ, reference allows < {allowed}"
+
+
+def test_oracle_flat_colour_known_answers(oracle_c1, golden_rgba):
+    """background / ambient-only PhongBlinn uint8(0.2*255.99)=51 / Standard frame uint8(150/255*255.99)=150:
+    jitter-independent away from edges, so nearly every golden pixel of that exact colour is exact here too."""
+    _, _, _, pix, _ = oracle_c1
+    for colour, count in (((0, 0, 0), 62209), ((51, 0, 0), 34104), ((150, 111, 51), 16572)):
+        gm = (golden_rgba[..., :3] == colour).all(-1)
+        om = (pix[..., :3] == colour).all(-1)
+        assert gm.sum() == count
+        assert (gm & om).sum() >= 0.97 * count, (colour, int((gm & om).sum()))
+        assert abs(int(om.sum()) - count) <= 0.01 * count
+    mean = pix[..., :3].reshape(-1, 3).mean(0)
+    assert np.allclose(mean, (55.8, 27.9, 33.2), atol=0.6)
+
+
+def test_oracle_ray_budget(oracle_c1):
+    """7.78 M primary rays, <= 32 shadow rays per PhongBlinn hit (2 positional lights x 16 reps)."""
+    _, spec, _, _, ctr = oracle_c1
+    assert ctr["rays_primary"] == 640 * 380 * 32
+    assert ctr["rays_shadow"] == ctr["phong_hits"] * 2 * spec.SoftShadowMonteCarloRepetitions
+
+
+def test_dfs_equals_dijkstra(bridge, c1):
+    """The reference test compares its two traversals (raytracer_test.go:28-29); with the same Philox
+    samples they must agree exactly."""
+    spec, scene = c1
+    s = copy.copy(spec)
+    s.Width, s.Height, s.AntiAliasingFactor = 160, 95, 4
+    with bridge.OracleScene(scene) as osc:
+        a, pa, _ = osc.render(s, mode=bridge.F64_DIJKSTRA)
+        b, pb, _ = osc.render(s, mode=bridge.F64_DFS)
+    assert np.array_equal(pa, pb)
+    assert np.abs(a - b).max() == 0.0
+
+
+def test_f32_mode_tracks_f64(bridge, c1):
+    spec, scene = c1
+    s = copy.copy(spec)
+    s.Width, s.Height, s.AntiAliasingFactor = 160, 95, 4
+    with bridge.OracleScene(scene) as osc:
+        a, pa, _ = osc.render(s, mode=bridge.F64_DIJKSTRA)
+        b, pb, _ = osc.render(s, mode=bridge.F32_STACK)
+    d = np.abs(pa.astype(int) - pb.astype(int))[..., :3].max(-1)
+    assert (d > 2).mean() < 0.005  # float32 flips a texel / checker / Schlick decision on a few pixels
+
+
+def test_trace_modes_agree_on_ids(bridge, c1):
+    spec, scene = c1
+    rng = np.random.default_rng(3)
+    n = 4000
+    px = np.stack([rng.integers(0, 640, n), rng.integers(0, 380, n), rng.integers(0, 32, n)], 1)
+    with bridge.OracleScene(scene) as osc:
+        rays = np.zeros((n, 8))
+        rays[:, :6] = osc.camera_rays(spec, px)
+        p0, t0 = osc.trace_rays(rays, mode=bridge.F64_DIJKSTRA)
+        p1, t1 = osc.trace_rays(rays, mode=bridge.F64_DFS)
+        p2, t2 = osc.trace_rays(rays, mode=bridge.F32_STACK)
+    assert np.array_equal(p0, p1)
+    assert (p0 != p2).mean() < 1e-3
+    hit = (p0 >= 0) & (p0 == p2)
+    assert np.allclose(t0[hit], t2[hit], rtol=1e-4)
+
+
+def test_sphere_far_root_quirk(bridge, rt):
+    """shape.go:64: a ray starting inside a sphere never hits it."""
+    scene = rt.Scene(CameraLookFrom=rt.Vec(0, 0, -5), CameraLookAt=rt.Vec(0, 0, 0), CameraUp=rt.Vec(0, 1, 0), CameraFov=60,
+                     Shapes=[rt.Sphere(rt.Vec(0, 0, 0), 1.0, rt.Standard(ColorFrac=rt.Vec(1, 0, 0)))], Lights=[])
+    rays = np.array([[0, 0, 0, 0, 0, 1, 0, 0], [0, 0, -3, 0, 0, 1, 0, 0]], dtype=np.float64)
+    with bridge.OracleScene(scene) as osc:
+        for mode in (0, 1, 2):
+            p, t = osc.trace_rays(rays, mode=mode)
+            assert p[0] == -1 and p[1] == 0 and abs(t[1] - 2.0) < 1e-6
+
+
+def test_scatter_known_answers(bridge, rt):
+    """Hand-computed single-ray answers for M1/M2/M3 (material.go:34-70)."""
+    V = rt.Vec
+    spec = rt.ImageSpec(8, 8, 1, 4, 1, 1, 0)
+
+    def one(mat, shape=None):
+        sh = shape or rt.TrianglePlane(V(-1, -1, 0), V(1, -1, 0), V(0, 1, 0), False, mat)
+        scene = rt.Scene(CameraLookFrom=V(0, 0, -5), CameraLookAt=V(0, 0, 0), CameraUp=V(0, 1, 0), CameraFov=60, Shapes=[sh], Lights=[])
+        with bridge.OracleScene(scene) as osc:
+            rc, out = osc.scatter_probe(spec, [0, 0, -2, 0, 0, 1])
+        assert rc == 0
+        return out
+
+    out = one(rt.Standard(ColorFrac=V(0.25, 0.5, 0.75)))
+    assert out[0] == 0 and np.allclose(out[10:13], (0.25, 0.5, 0.75)) and abs(out[13] - 2.0) < 1e-12
+    # triangle normal = Unit((B-A) x (C-A)) = +z; the ray travels along +z so reflected.n = -1 < 0: no trace
+    out = one(rt.Metal(Albedo=V(1, 1, 1), Fuzz=0))
+    assert out[0] == 0 and np.allclose(out[17:20], (0, 0, 1))
+    # flipped winding: normal -z, mirror reflection back along -z
+    out = one(None, rt.TrianglePlane(V(-1, -1, 0), V(0, 1, 0), V(1, -1, 0), False, rt.Metal(Albedo=V(0.5, 0.6, 0.7), Fuzz=0)))
+    assert out[0] == 1 and np.allclose(out[1:4], (0.5, 0.6, 0.7)) and np.allclose(out[7:10], (0, 0, -1)) and np.allclose(out[4:7], (0, 0, 0))
+    # Dielectric at normal incidence from outside (d.n < 0): ratio 1/RI; straight through or straight back, origin offset 1e-5*dir
+    out = one(None, rt.TrianglePlane(V(-1, -1, 0), V(0, 1, 0), V(1, -1, 0), False, rt.Dielectric(RefractiveIndex=1.5)))
+    assert out[0] == 1 and np.allclose(out[1:4], (1, 1, 1)) and abs(abs(out[9]) - 1) < 1e-9 and abs(out[6] - 1e-5 * out[9]) < 1e-12
