@@ -508,8 +508,9 @@ bool trace_dfs(const Scene& sc, const Ray<double>& r, double tmin, Hit<double>& 
 // F32_STACK: the device traversal restated on the pointer tree.
 //   - child boxes tested with the FMA slab form t = fma(b, 1/d, -(o * 1/d)), IEEE
 //     minNum/maxNum folding, clipped to [0 (or tMin), best];
-//   - children visited in ray order k = 0..7, octant o = k ^ signmask; leaf children are
-//     intersected inline, hit inner children are pushed far-to-near and popped near-first;
+//   - per node: every present child's box is tested against the best t at node entry, in ray
+//     order k = 0..7, octant o = k ^ signmask; then the hit leaf children are intersected in
+//     that order; then hit inner children are pushed far-to-near and the nearest is entered;
 //   - nearest hit accepted with the reference's rule t > 0 && t < best (strict);
 //   - any_hit: stop at the first accepted t <= tmax.
 // ------------------------------------------------------------------------------------
@@ -879,6 +880,9 @@ V3<R> color(const Tracer<R>& trc_in, Ray<R> r, int max_depth, int reps, const Rn
     Tracer<R> trc = trc_in;
     for (int depth = 0;; ++depth) {
         Hit<R> hit;
+        // The reference still traces a ray at depth == max_depth and then discards the hit
+        // (raytracer.go:143-145); the device path does not launch that ray, and neither does F32_STACK.
+        if (!std::is_same<R, double>::value && depth >= max_depth) return {0, 0, 0};
         if (rc) { if (depth == 0) rc->primary++; else rc->continuation++; }
         trc.tc = rc ? (depth == 0 ? &rc->tc_primary : &rc->tc_continuation) : nullptr;
         const bool got = trc.trace(r, (R)0.0, hit);
