@@ -213,6 +213,85 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
     return best_prim >= 0;
 }
 
+// ---- wavefront-packet any-hit traversal (shadow rays) ----------------------------------------
+// The 64 shadow rays of a wavefront go to the same light from neighbouring hit points, so they
+// walk nearly the same nodes.  The traversal is therefore WAVE-UNIFORM: one stack per wavefront
+// (LDS), a node is entered when any live lane hits its box, and node / shape data are fetched with
+// SCALAR loads (constant address space -> s_load through the scalar cache) instead of 64 per-lane
+// copies through the vector L1 — the per-lane form is bound by vector-memory return bandwidth.
+// Per lane the outcome is the same as traverse<true>: a lane tests a shape iff it hits that leaf's
+// box (child boxes are nested in their parents' and the slab test is monotone, so it then hits
+// every ancestor too), and "occluded" is an OR over those tests, which has no order.
+#define RT_CONST __attribute__((address_space(4)))
+typedef float v8f __attribute__((ext_vector_type(8)));  // one child record: {min.xyz, max.xyz, w0, w1}
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <class T> RT_DEV const RT_CONST T* as_constant(const void* p) {
+    return (const RT_CONST T*)(uintptr_t)p;
+}
+constexpr int kPacketStackDepth = 128;  // entries per wavefront in LDS
+
+// alive: this lane has a ray.  Returns true if this lane's ray is occluded.
+RT_DEV bool packet_occluded(const DScene& S, uint32_t* wave_stack, bool alive, f3 o, f3 d, float tmin, float tmax) {
+    const RT_CONST v8f* recs = as_constant<v8f>(S.recs);
+    const RT_CONST v4f* prims = as_constant<v4f>(S.prims);
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 oi = mk3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+    unsigned long long live = __ballot(alive);
+    if (live == 0ull) return false;
+    // ray order of the first live lane: any order is valid for any-hit, near-first exits sooner
+    const uint32_t my_sign = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    const uint32_t sign = (uint32_t)__builtin_amdgcn_readlane((int)my_sign, __ffsll((long long)live) - 1);
+    bool occluded = false;
+    uint32_t cur = S.root_ref;
+    int sp = 0;
+    for (;;) {
+        const uint32_t first = cur >> 8, present = cur & 0xffu;
+        for (int k = 7; k >= 0; --k) {  // far to near: the nearest inner child ends on top of the stack
+            const uint32_t oct = (uint32_t)k ^ sign;
+            if (!((present >> oct) & 1u)) continue;
+            const uint32_t idx = first + (uint32_t)__builtin_popcount(present & ((1u << oct) - 1u));
+            const v8f r = recs[idx];
+            const uint32_t w0 = __float_as_uint(r[6]), w1 = __float_as_uint(r[7]);
+            float tn = 0.0f, tf = tmax;
+            {
+                const float lo = fmaf(r[0], inv.x, -oi.x), hi = fmaf(r[3], inv.x, -oi.x);
+                tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+            }
+            {
+                const float lo = fmaf(r[1], inv.y, -oi.y), hi = fmaf(r[4], inv.y, -oi.y);
+                tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+            }
+            {
+                const float lo = fmaf(r[2], inv.z, -oi.z), hi = fmaf(r[5], inv.z, -oi.z);
+                tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+            }
+            const bool hit = alive && !occluded && tn <= tf;
+            if (__ballot(hit) == 0ull) continue;
+            if (w1 & kLeaf) {
+                const v4f p0 = prims[3 * (size_t)w0], p1 = prims[3 * (size_t)w0 + 1], p2 = prims[3 * (size_t)w0 + 2];
+                const uint32_t bits = __float_as_uint(p2[1]);
+                if (hit) {
+                    float t;
+                    if (bits & kPrimTriangle)
+                        t = triangle_hit(mk3(p0[0], p0[1], p0[2]), mk3(p0[3], p1[0], p1[1]), mk3(p1[2], p1[3], p2[0]),
+                                         (bits & kPrimSingleSided) != 0, o, d, tmin, tmax);
+                    else
+                        t = sphere_hit(make_float4(p0[0], p0[1], p0[2], p0[3]), o, d, tmin, tmax);
+                    if (t > 0.0f && t <= tmax) occluded = true;
+                }
+            } else {
+                if (sp < kPacketStackDepth) wave_stack[sp] = w0;  // bound checked on the host
+                ++sp;
+            }
+        }
+        live = __ballot(alive && !occluded);
+        if (live == 0ull || sp == 0) break;
+        --sp;
+        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_stack[sp]);
+    }
+    return occluded;
+}
+
 // ---- textures (texture.go:27-53) and UV maps (shape.go:100-105, 213-227) --------------------
 RT_DEV long long floor_to_int(float x) {
     if (!(x == x)) return 0;

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -225,12 +226,16 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, Batch B, Work Wk, co
 // One lane per (PhongBlinn hit, positional light, repetition lane).  group = lanes per (hit, light):
 // a power of two <= 64; each lane runs repetitions r, r+group, ...  The visible repetitions of a
 // (hit, light) are counted with a ballot popcount: integer, so the result has no summation order.
-__global__ __launch_bounds__(kBlock) void k_shadow(DScene S, Batch B, Work Wk, uint32_t n_hits, int bounce,
+// PACKET: wave-uniform traversal with scalar node loads (device_math.hpp packet_occluded); the
+// per-lane form remains for trees whose stack bound exceeds the wavefront stack in LDS.
+template <bool PACKET>
+__global__ __launch_bounds__(kBlock, 4) void k_shadow(DScene S, Batch B, Work Wk, uint32_t n_hits, int bounce,
                                                    int group, int group_shift) {
-    __shared__ uint32_t s_stack[kLdsStackDepth * kBlock];
+    __shared__ uint32_t s_stack[PACKET ? (kBlock / 64) * kPacketStackDepth : kLdsStackDepth * kBlock];
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlock;
     const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride};
+    uint32_t* wave_stack = s_stack + (threadIdx.x >> 6) * kPacketStackDepth;
     const unsigned long long total = (unsigned long long)n_hits * S.n_pos_lights * group;
     const unsigned long long rounds = (total + gstride - 1) / gstride;
     const int lane = (int)__lane_id();
@@ -247,9 +252,11 @@ __global__ __launch_bounds__(kBlock) void k_shadow(DScene S, Batch B, Work Wk, u
         L.kind = 0;
         if (active) {
             r = (uint32_t)(idx & (unsigned long long)(group - 1));
+            // light-major order: the lane groups of a wavefront are consecutive hits (neighbouring
+            // pixels / samples) towards the SAME light, so all 64 shadow rays are nearly parallel
             const unsigned long long hl = idx >> group_shift;
-            hit_i = (uint32_t)(hl / S.n_pos_lights);
-            lp = (uint32_t)(hl - (unsigned long long)hit_i * S.n_pos_lights);
+            lp = (uint32_t)(hl / n_hits);
+            hit_i = (uint32_t)(hl - (unsigned long long)lp * n_hits);
             const uint32_t slot = Wk.phong_queue[hit_i];
             const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
             p = add3(mk3(ro.x, ro.y, ro.z), scale3(ro.w, mk3(rdv.x, rdv.y, rdv.z)));
@@ -269,7 +276,9 @@ __global__ __launch_bounds__(kBlock) void k_shadow(DScene S, Batch B, Work Wk, u
         for (int itn = 0; itn < iters; ++itn) {
             // every lane of the wavefront runs the same number of rounds so the ballot is convergent
             const uint32_t rep = r + (uint32_t)itn * (uint32_t)group;
-            bool vis = false;
+            bool vis = false, traced = false;
+            f3 dir = mk3(1.0f, 1.0f, 1.0f);
+            float dist = 0.0f;
             if (active && rep < (uint32_t)B.reps) {
                 const f3 jit = scale3(0.25f, random_in_unit_sphere(key, (uint32_t)bounce, P_SHADOW, lp * (uint32_t)B.reps + rep));
                 const f3 shifted = add3(ld3(L.pos), jit);  // light.go:94 / :123
@@ -278,12 +287,17 @@ __global__ __launch_bounds__(kBlock) void k_shadow(DScene S, Batch B, Work Wk, u
                     in_cone = dot3(ld3(L.look_dir), unit3(sub3(p, shifted))) >= L.cos_angle;
                 if (in_cone) {
                     ++launched;
+                    traced = true;
                     const f3 ld = sub3(shifted, p);  // doesReachLight, light.go:141-160
-                    const float dist = norm3(ld);
-                    float t; int prim;
-                    vis = !traverse<true>(S, st, p, scale3(1.0f / dist, ld), 0.01f, dist, &t, &prim);
+                    dist = norm3(ld);
+                    dir = scale3(1.0f / dist, ld);
+                    if (!PACKET) {
+                        float t; int prim;
+                        vis = !traverse<true>(S, st, p, dir, 0.01f, dist, &t, &prim);
+                    }
                 }
             }
+            if (PACKET) vis = traced && !packet_occluded(S, wave_stack, traced, p, dir, 0.01f, dist);
             const unsigned long long m = __ballot(vis);
             count += (uint32_t)__popcll(m & gmask);
         }
@@ -785,7 +799,13 @@ int rt_render_accum_device(rt_scene* s, const rt_image_spec* spec, const rt_part
                         if (timed) HIP_TRY(hipEventRecord(ev[3], stream));
                         if (s->d.n_pos_lights > 0 && reps > 0) {
                             const unsigned long long lanes = (unsigned long long)np * s->d.n_pos_lights * group;
-                            hipLaunchKernelGGL(k_shadow, dim3(grid_for(lanes)), dim3(kBlock), 0, stream, s->d, B, wk, np, b, group, group_shift);
+                            // The per-lane form measured faster on config 3 (2.71 s vs 3.08 s per frame): the packet form
+                            // serialises the union of the nodes its 64 rays touch and becomes scalar-ALU bound.
+                            static const bool use_packet = std::getenv("RTGO_SHADOW_PACKET") != nullptr;  // A/B switch
+                            if (s->info.stack_bound <= kPacketStackDepth && use_packet)
+                                hipLaunchKernelGGL(k_shadow<true>, dim3(grid_for(lanes)), dim3(kBlock), 0, stream, s->d, B, wk, np, b, group, group_shift);
+                            else
+                                hipLaunchKernelGGL(k_shadow<false>, dim3(grid_for(lanes)), dim3(kBlock), 0, stream, s->d, B, wk, np, b, group, group_shift);
                         } else if (s->d.n_pos_lights > 0) {
                             HIP_TRY(hipMemsetAsync(wk.vis, 0, (size_t)np * s->d.n_pos_lights * sizeof(uint32_t), stream));
                         }
