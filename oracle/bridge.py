@@ -50,6 +50,7 @@ def lib():
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_create.argtypes = [C.c_void_p]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_set_leaf_size.argtypes = [C.c_void_p, C.c_int]
         L.orc_tree_info.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_trace_rays.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -72,6 +73,8 @@ class OracleScene:
         self._h = lib().orc_scene_create(C.addressof(self._flat.desc))
         if not self._h:
             raise RuntimeError(lib().orc_last_error().decode())
+        # F32_STACK mirrors the device tree: same shapes-per-leaf rule as the device flattener
+        lib().orc_set_leaf_size(self._h, int(os.environ.get("RTGO_LEAF_SIZE", "4")))
 
     def close(self):
         if self._h:

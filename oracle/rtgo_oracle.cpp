@@ -169,6 +169,7 @@ struct Node {
     bool has_children = false;
     // F32_STACK helpers (filled after the build)
     float fmin[3], fmax[3];
+    int count = 0;  // shapes in the subtree
 };
 
 struct Scene {
@@ -180,6 +181,7 @@ struct Scene {
     double aperture, fov;
     std::vector<std::unique_ptr<Node>> pool;
     Node* root = nullptr;
+    int leaf_size = 4;  // F32_STACK: a subtree with at most this many shapes is one leaf (device flattener rule)
     int n_nodes_alloc = 0;
 };
 
@@ -317,8 +319,14 @@ inline float round_up(double x) {
 void fill_f32_boxes(Node* n) {
     n->fmin[0] = round_down(n->pmin.x); n->fmin[1] = round_down(n->pmin.y); n->fmin[2] = round_down(n->pmin.z);
     n->fmax[0] = round_up(n->pmax.x);   n->fmax[1] = round_up(n->pmax.y);   n->fmax[2] = round_up(n->pmax.z);
+    n->count = (n->leaf && n->shape >= 0) ? 1 : 0;
     if (n->has_children)
-        for (Node* c : n->children) if (c) fill_f32_boxes(c);
+        for (Node* c : n->children) if (c) { fill_f32_boxes(c); n->count += c->count; }
+}
+// shapes of a subtree, depth first in octant order (the order of a device leaf's shapes)
+void subtree_shapes(const Node* n, std::vector<int>* out) {
+    if (n->leaf) { if (n->shape >= 0) out->push_back(n->shape); return; }
+    for (const Node* c : n->children) if (c) subtree_shapes(c, out);
 }
 // Follow single-child chains: after the refit a node with one non-nil child has exactly that
 // child's box, so the device flattener drops it; the F32_STACK traversal does the same.
@@ -544,12 +552,14 @@ bool trace_stack_f32(const Scene& sc, const Ray<float>& r, float tmin, float tma
     bool found = false;
     std::vector<Node*> stack;
     Node* root = effective(sc.root);
-    Node fake;  // a leaf root gets a synthetic one-child parent, as in the device flattener
-    if (root->leaf) {
-        if (root->shape < 0) { out = hr; return false; }
+    const int leaf_size = sc.leaf_size < 1 ? 1 : sc.leaf_size;
+    Node fake;  // a root that is itself one leaf gets a synthetic one-child parent, as in the device flattener
+    if (root->count <= leaf_size) {
+        if (root->count == 0) { out = hr; return false; }
         fake.leaf = false; fake.has_children = true; fake.children[0] = root;
         root = &fake;
     }
+    std::vector<int> group;
     Node* cur = root;
     const float t0 = 0.0f;
     for (;;) {
@@ -564,15 +574,19 @@ bool trace_stack_f32(const Scene& sc, const Ray<float>& r, float tmin, float tma
             // box of the slot is the box of the un-collapsed child (identical after refit)
             Node* e = effective(c);
             if (!slab_f32(sr, e->fmin, e->fmax, t0, entry_best)) continue;
-            if (e->leaf) leaves[nl++] = e; else pending[np++] = e;
+            if (e->count <= leaf_size) leaves[nl++] = e; else pending[np++] = e;
         }
-        // pass 2: hit leaf children intersected in ray order
+        // pass 2: hit leaf children in ray order; a leaf's shapes in their stored (depth-first) order
         for (int q = 0; q < nl; ++q) {
-            if (tc) tc->leaf++;
-            const Hit<float> sh = shape_hit(sc.t32, leaves[q]->shape, r, tmin, hr.t);
-            if (any_hit) {
-                if (sh.t > 0.0f && sh.t <= hr.t) { out = sh; return true; }
-            } else if (sh.t > 0.0f && sh.t < hr.t) { hr = sh; found = true; }
+            group.clear();
+            subtree_shapes(leaves[q], &group);
+            for (int shape : group) {
+                if (tc) tc->leaf++;
+                const Hit<float> sh = shape_hit(sc.t32, shape, r, tmin, hr.t);
+                if (any_hit) {
+                    if (sh.t > 0.0f && sh.t <= hr.t) { out = sh; return true; }
+                } else if (sh.t > 0.0f && sh.t < hr.t) { hr = sh; found = true; }
+            }
         }
         for (int i = np - 1; i >= 1; --i) stack.push_back(pending[i]);
         if (np > 0) { cur = pending[0]; continue; }
@@ -969,6 +983,8 @@ orc_scene* orc_scene_create(const rt_scene_desc* d) {
     return o;
 }
 void orc_scene_destroy(orc_scene* s) { delete s; }
+// F32_STACK only: shapes per leaf of the device tree being mirrored (RTGO_LEAF_SIZE, default 4)
+void orc_set_leaf_size(orc_scene* s, int leaf_size) { s->sc.leaf_size = leaf_size; }
 
 // out[0] = pointer-tree node count, out[1] = inner nodes (non-leaf, after prune), out[2] = max depth
 void orc_tree_info(const orc_scene* s, int64_t* out) {

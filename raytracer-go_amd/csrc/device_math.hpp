@@ -75,7 +75,8 @@ constexpr uint32_t kPrimSingleSided = 2u;
 
 struct DScene {
     const float4* recs;    // 2 float4 per child record: {min.xyz, max.x}, {max.y, max.z, w0, w1}
-    const float4* prims;   // 3 float4 per shape: tri {A, B.x}{B.yz, C.xy}{C.z, bits, -, -}; sphere {C, R}{-}{-, bits}
+    const float4* prims;   // 3 float4 per shape, in LEAF order: tri {A, B.x}{B.yz, C.xy}{C.z, bits, -, -}; sphere {C, R}{-}{-, bits}
+    const int* prim_ids;   // leaf-order shape q -> position in Scene.Shapes
     const DMaterial* materials;
     const DTexture* textures;
     const DLight* lights;
@@ -188,13 +189,17 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
         while (leaf_mask) {
             const int k = __ffs((int)leaf_mask) - 1;
             leaf_mask &= leaf_mask - 1u;
-            uint32_t prim = ref[0];
+            uint32_t leaf = ref[0];
 #pragma unroll
-            for (int q = 1; q < 8; ++q) prim = (k == q) ? ref[q] : prim;
-            const float t = prim_hit(S, prim, o, d, tmin, best);
-            if (ANY) {
-                if (t > 0.0f && t <= best) { *t_out = t; *prim_out = (int)prim; return true; }
-            } else if (t > 0.0f && t < best) { best = t; best_prim = (int)prim; }
+            for (int q = 1; q < 8; ++q) leaf = (k == q) ? ref[q] : leaf;
+            const uint32_t pfirst = leaf >> 8, pcount = leaf & 0xffu;  // the leaf's shapes, contiguous
+            for (uint32_t c = 0; c < pcount; ++c) {
+                const uint32_t prim = pfirst + c;
+                const float t = prim_hit(S, prim, o, d, tmin, best);
+                if (ANY) {
+                    if (t > 0.0f && t <= best) { *t_out = t; *prim_out = (int)prim; return true; }
+                } else if (t > 0.0f && t < best) { best = t; best_prim = (int)prim; }
+            }
         }
         if (inner_mask) {
             // far-to-near pushes of everything but the nearest, which is entered directly
@@ -268,9 +273,12 @@ RT_DEV bool packet_occluded(const DScene& S, uint32_t* wave_stack, bool alive, f
             const bool hit = alive && !occluded && tn <= tf;
             if (__ballot(hit) == 0ull) continue;
             if (w1 & kLeaf) {
-                const v4f p0 = prims[3 * (size_t)w0], p1 = prims[3 * (size_t)w0 + 1], p2 = prims[3 * (size_t)w0 + 2];
+              const uint32_t pfirst = w0 >> 8, pcount = w0 & 0xffu;
+              for (uint32_t c = 0; c < pcount; ++c) {
+                const size_t pi = (size_t)(pfirst + c);
+                const v4f p0 = prims[3 * pi], p1 = prims[3 * pi + 1], p2 = prims[3 * pi + 2];
                 const uint32_t bits = __float_as_uint(p2[1]);
-                if (hit) {
+                if (hit && !occluded) {
                     float t;
                     if (bits & kPrimTriangle)
                         t = triangle_hit(mk3(p0[0], p0[1], p0[2]), mk3(p0[3], p1[0], p1[1]), mk3(p1[2], p1[3], p2[0]),
@@ -279,6 +287,7 @@ RT_DEV bool packet_occluded(const DScene& S, uint32_t* wave_stack, bool alive, f
                         t = sphere_hit(make_float4(p0[0], p0[1], p0[2], p0[3]), o, d, tmin, tmax);
                     if (t > 0.0f && t <= tmax) occluded = true;
                 }
+              }
             } else {
                 if (sp < kPacketStackDepth) wave_stack[sp] = w0;  // bound checked on the host
                 ++sp;

@@ -149,34 +149,60 @@ std::vector<HostNode> build_octree(const rt_shape* shapes, int64_t n) {
         HostNode& nd = nodes[k];
         if (nd.child_base < 0) {
             nd.empty = nd.shape < 0;
+            nd.n_shapes = nd.empty ? 0 : 1;
             if (!nd.empty) shape_bounds(shapes[nd.shape], nd.lo, nd.hi);
             continue;
         }
         nd.empty = true;
+        nd.n_shapes = 0;
         for (int a = 0; a < 3; ++a) { nd.lo[a] = DBL_MAX; nd.hi[a] = -9223372036854775808.0; }
         for (int o = 0; o < 8; ++o) {
             const HostNode& c = nodes[nd.child_base + o];
             if (c.empty) continue;
             nd.empty = false;
+            nd.n_shapes += c.n_shapes;
             for (int a = 0; a < 3; ++a) { nd.lo[a] = std::fmin(nd.lo[a], c.lo[a]); nd.hi[a] = std::fmax(nd.hi[a], c.hi[a]); }
         }
     }
     return nodes;
 }
 
-bool flatten_octree(const std::vector<HostNode>& nodes, FlatTree* out, const char** err) {
+// depth-first, octant order
+static void collect_shapes(const std::vector<HostNode>& nodes, int32_t n, std::vector<int32_t>* out) {
+    if (nodes[n].child_base < 0) {
+        if (nodes[n].shape >= 0) out->push_back(nodes[n].shape);
+        return;
+    }
+    for (int o = 0; o < 8; ++o)
+        if (!nodes[nodes[n].child_base + o].empty) collect_shapes(nodes, nodes[n].child_base + o, out);
+}
+
+bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree* out, const char** err) {
     out->records.clear();
+    out->order.clear();
     out->root_ref = 0; out->n_inner = 0; out->depth = 0; out->stack_bound = 1;
     if (nodes.empty() || nodes[0].empty) return true;  // no shapes: present mask 0 => every ray misses
+    if (leaf_size < 1) leaf_size = 1;
+    if (leaf_size > kMaxLeafSize) leaf_size = kMaxLeafSize;
+
+    auto make_leaf = [&](int32_t e, ChildRecord* r) {
+        const uint32_t first = (uint32_t)out->order.size();
+        collect_shapes(nodes, e, &out->order);
+        r->w0 = (first << 8) | (uint32_t)(out->order.size() - first);
+        r->w1 = kLeafFlag;
+    };
+    auto set_box = [&](int32_t e, ChildRecord* r) {
+        for (int a = 0; a < 3; ++a) { r->bmin[a] = round_down_f32(nodes[e].lo[a]); r->bmax[a] = round_up_f32(nodes[e].hi[a]); }
+    };
 
     struct Pending { int32_t node; int64_t patch; int32_t level; };  // patch = record whose w0 names this block
     std::deque<Pending> queue;
     const int32_t root = skip_chain(nodes, 0);
-    if (nodes[root].child_base < 0) {
-        // A single shape: synthetic root block with one leaf record in octant 0.
+    if (nodes[root].n_shapes <= leaf_size) {
+        // everything fits one leaf: synthetic root block with that leaf in octant 0
         ChildRecord r;
-        for (int a = 0; a < 3; ++a) { r.bmin[a] = round_down_f32(nodes[root].lo[a]); r.bmax[a] = round_up_f32(nodes[root].hi[a]); }
-        r.w0 = (uint32_t)nodes[root].shape; r.w1 = kLeafFlag;
+        set_box(root, &r);
+        make_leaf(root, &r);
         out->records.push_back(r);
         out->root_ref = (0u << 8) | 1u;
         out->n_inner = 1; out->depth = 1; out->stack_bound = 8;
@@ -195,16 +221,16 @@ bool flatten_octree(const std::vector<HostNode>& nodes, FlatTree* out, const cha
             present |= 1u << o;
             const int32_t e = skip_chain(nodes, c);
             ChildRecord r;
-            for (int a = 0; a < 3; ++a) { r.bmin[a] = round_down_f32(nodes[e].lo[a]); r.bmax[a] = round_up_f32(nodes[e].hi[a]); }
-            if (nodes[e].child_base < 0) {
-                r.w0 = (uint32_t)nodes[e].shape; r.w1 = kLeafFlag;
+            set_box(e, &r);
+            if (nodes[e].n_shapes <= leaf_size) {
+                make_leaf(e, &r);
             } else {
                 r.w0 = 0; r.w1 = 0;
                 queue.push_back({e, (int64_t)out->records.size(), p.level + 1});
             }
             out->records.push_back(r);
         }
-        if ((int64_t)out->records.size() > kMaxChildRecords) {
+        if ((int64_t)out->records.size() > kMaxChildRecords || (int64_t)out->order.size() >= kMaxChildRecords) {
             *err = "scene too large: the flattened octree exceeds 2^24 child records";
             return false;
         }

@@ -12,8 +12,12 @@
 //     omitted; blocks are laid out breadth-first so the top of the tree is contiguous;
 //   - a chain of nodes with a single non-empty child is dropped: after the refit such a node
 //     has exactly its child's box, so removing it cannot change any hit;
+//   - a subtree that holds at most `leaf_size` shapes becomes ONE leaf record listing those shapes
+//     (depth-first, octant order); shapes are re-ordered so that a leaf's shapes are contiguous
+//     (`order[q]` = position in Scene.Shapes of re-ordered shape q).  leaf_size = 1 keeps the
+//     reference's one-shape-per-leaf tree;
 //   - inner child : w0 = (first record of its block << 8) | 8-bit octant-present mask, w1 = 0
-//     leaf child  : w0 = shape index (= position in Scene.Shapes), w1 = kLeafFlag.
+//     leaf child  : w0 = (first re-ordered shape << 8) | shape count, w1 = kLeafFlag.
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -23,13 +27,15 @@
 namespace rtgo {
 
 constexpr uint32_t kLeafFlag = 0x80000000u;
-constexpr int64_t kMaxChildRecords = (int64_t)1 << 24;  // w0 keeps 24 bits for the block index
+constexpr int64_t kMaxChildRecords = (int64_t)1 << 24;  // w0 keeps 24 bits for the block / shape index
+constexpr int kMaxLeafSize = 255;
 
 struct HostNode {
     double lo[3], hi[3];  // cell bounds while inserting, tight bounds after refit()
     int32_t shape = -1;   // leaf payload, -1 = empty
     int32_t child_base = -1;  // index of the first of 8 consecutive children, -1 = leaf
     bool empty = true;    // after refit(): subtree holds no shape
+    int32_t n_shapes = 0; // after refit(): shapes in the subtree
 };
 
 struct ChildRecord {  // 32 bytes, read by the kernels as two float4
@@ -40,6 +46,7 @@ struct ChildRecord {  // 32 bytes, read by the kernels as two float4
 
 struct FlatTree {
     std::vector<ChildRecord> records;
+    std::vector<int32_t> order;  // re-ordered shape q -> index in Scene.Shapes
     uint32_t root_ref = 0;  // (first << 8) | present of the root block
     int64_t n_inner = 0;    // blocks
     int32_t depth = 0;      // levels of blocks below the root (root block = 1)
@@ -49,6 +56,6 @@ struct FlatTree {
 // shapes: desc->shapes[0..n). Returns nodes[0] = root.
 std::vector<HostNode> build_octree(const rt_shape* shapes, int64_t n);
 // Returns false (and sets *err) if the tree exceeds kMaxChildRecords.
-bool flatten_octree(const std::vector<HostNode>& nodes, FlatTree* out, const char** err);
+bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree* out, const char** err);
 
 }  // namespace rtgo
