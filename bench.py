@@ -57,11 +57,19 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # one rank per GPU; on a box with fewer GPUs than ranks (rehearsal only) ranks share devices and the
+    # reduce goes through gloo, since RCCL refuses two ranks on one device
+    n_dev = torch.cuda.device_count()
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend_name = os.environ.get("RTGO_DIST_BACKEND", "nccl" if n_dev >= world else "gloo")
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend_name, rank=rank, world_size=world)
 
     spec, scene = scenes.config3(args.width, args.height, args.spp, 16, asset_dir=GOLD)
     dscene = backend.DeviceScene(scene, device=local_rank)

@@ -115,11 +115,12 @@ RT_DEV float triangle_hit(f3 A, f3 B, f3 C, bool single_sided, f3 o, f3 d, float
     return t;
 }
 RT_DEV float prim_hit(const DScene& S, uint32_t prim, f3 o, f3 d, float tmin, float tmax) {
+    // all three quads are fetched together (a sphere ignores p1): one memory latency per shape
     const float4 p0 = S.prims[3 * (size_t)prim];
+    const float4 p1 = S.prims[3 * (size_t)prim + 1];
     const float4 p2 = S.prims[3 * (size_t)prim + 2];
     const uint32_t bits = __float_as_uint(p2.y);
     if (bits & kPrimTriangle) {
-        const float4 p1 = S.prims[3 * (size_t)prim + 1];
         return triangle_hit(mk3(p0.x, p0.y, p0.z), mk3(p0.w, p1.x, p1.y), mk3(p1.z, p1.w, p2.x),
                             (bits & kPrimSingleSided) != 0, o, d, tmin, tmax);
     }
@@ -160,13 +161,24 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
         uint32_t ref[8];
         uint32_t leaf_mask = 0, inner_mask = 0;  // bit k = ray-order position
         const float entry_best = best;
+        // All child records are fetched before any is tested, with no branch around the loads (an
+        // absent child re-reads the block's first record): one memory latency per node instead of one
+        // per present child.
+        float4 ra[8], rb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t oct = (uint32_t)k ^ sign;
+            const uint32_t below = (uint32_t)__popc(present & ((1u << oct) - 1u));
+            const size_t idx = (size_t)first + (((present >> oct) & 1u) ? below : 0u);
+            ra[k] = S.recs[2 * idx];
+            rb[k] = S.recs[2 * idx + 1];
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t oct = (uint32_t)k ^ sign;
             ref[k] = 0;
             if ((present >> oct) & 1u) {
-                const size_t idx = (size_t)first + __popc(present & ((1u << oct) - 1u));
-                const float4 a = S.recs[2 * idx], b = S.recs[2 * idx + 1];
+                const float4 a = ra[k], b = rb[k];
                 float tn = 0.0f, tf = entry_best;
                 {
                     const float lo = fmaf(a.x, inv.x, -oi.x), hi = fmaf(a.w, inv.x, -oi.x);

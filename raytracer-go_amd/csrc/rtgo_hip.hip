@@ -246,41 +246,34 @@ __global__ __launch_bounds__(kBlock, 4) void k_shadow(DScene S, Batch B, Work Wk
     for (unsigned long long it = 0; it < rounds; ++it) {
         const unsigned long long idx = it * gstride + gtid;
         const bool active = idx < total;
-        uint32_t r = 0, hit_i = 0, lp = 0;
-        f3 p = mk3(0, 0, 0);
-        RngKey key{B.k0, B.k1, 0, 0};
-        DLight L;
-        L.kind = 0;
-        if (active) {
-            r = (uint32_t)(idx & (unsigned long long)(group - 1));
-            // light-major order: the lane groups of a wavefront are consecutive hits (neighbouring
-            // pixels / samples) towards the SAME light, so all 64 shadow rays are nearly parallel
-            const unsigned long long hl = idx >> group_shift;
-            lp = (uint32_t)(hl / n_hits);
-            hit_i = (uint32_t)(hl - (unsigned long long)lp * n_hits);
-            const uint32_t slot = Wk.phong_queue[hit_i];
-            const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
-            p = add3(mk3(ro.x, ro.y, ro.z), scale3(ro.w, mk3(rdv.x, rdv.y, rdv.z)));
-            const long long lpl = (long long)slot / B.ns;
-            int x, row;
-            pixel_of(B, B.lp0 + lpl, &x, &row);
-            key.pixel = (uint32_t)(row * B.W + x);
-            key.sample = (uint32_t)(B.s0 + (int)(slot - lpl * B.ns));
-            // positional light #lp
-            int seen = -1;
-            for (int q = 0; q < S.n_lights; ++q) {
-                if (S.lights[q].kind != RT_LIGHT_AMBIENT && ++seen == (int)lp) { L = S.lights[q]; break; }
-            }
-        }
+        // light-major order: the lane groups of a wavefront are consecutive hits (neighbouring
+        // pixels / samples) towards the SAME light, so all 64 shadow rays are nearly parallel
+        const uint32_t r = (uint32_t)(idx & (unsigned long long)(group - 1));
+        const unsigned long long hl = idx >> group_shift;
+        const uint32_t lp = active ? (uint32_t)(hl / n_hits) : 0u;
+        const uint32_t hit_i = active ? (uint32_t)(hl - (unsigned long long)lp * n_hits) : 0u;
         uint32_t count = 0;
         const int iters = (B.reps + group - 1) >> group_shift;  // > 1 only when reps > 64
         for (int itn = 0; itn < iters; ++itn) {
             // every lane of the wavefront runs the same number of rounds so the ballot is convergent
             const uint32_t rep = r + (uint32_t)itn * (uint32_t)group;
             bool vis = false, traced = false;
-            f3 dir = mk3(1.0f, 1.0f, 1.0f);
+            f3 p = mk3(0.0f, 0.0f, 0.0f), dir = mk3(1.0f, 1.0f, 1.0f);
             float dist = 0.0f;
             if (active && rep < (uint32_t)B.reps) {
+                // everything about the ray is derived here, so nothing but (hit, light, rep) stays live
+                // across the traversal below
+                const uint32_t slot = Wk.phong_queue[hit_i];
+                const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
+                p = add3(mk3(ro.x, ro.y, ro.z), scale3(ro.w, mk3(rdv.x, rdv.y, rdv.z)));
+                const uint32_t lpl = slot / (uint32_t)B.ns;
+                int x, row;
+                pixel_of(B, B.lp0 + lpl, &x, &row);
+                const RngKey key{B.k0, B.k1, (uint32_t)(row * B.W + x), (uint32_t)B.s0 + (slot - lpl * (uint32_t)B.ns)};
+                int q = 0;  // positional light #lp
+                for (int seen = -1; q < S.n_lights; ++q)
+                    if (S.lights[q].kind != RT_LIGHT_AMBIENT && ++seen == (int)lp) break;
+                const DLight& L = S.lights[q];
                 const f3 jit = scale3(0.25f, random_in_unit_sphere(key, (uint32_t)bounce, P_SHADOW, lp * (uint32_t)B.reps + rep));
                 const f3 shifted = add3(ld3(L.pos), jit);  // light.go:94 / :123
                 bool in_cone = true;
@@ -292,13 +285,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_shadow(DScene S, Batch B, Work Wk
                     const f3 ld = sub3(shifted, p);  // doesReachLight, light.go:141-160
                     dist = norm3(ld);
                     dir = scale3(1.0f / dist, ld);
-                    if (!PACKET) {
-                        float t; int prim;
-                        vis = !traverse<true>(S, st, p, dir, 0.01f, dist, &t, &prim);
-                    }
                 }
             }
-            if (PACKET) vis = traced && !packet_occluded(S, wave_stack, traced, p, dir, 0.01f, dist);
+            if (PACKET) {
+                vis = traced && !packet_occluded(S, wave_stack, traced, p, dir, 0.01f, dist);
+            } else if (traced) {
+                float t; int prim;
+                vis = !traverse<true>(S, st, p, dir, 0.01f, dist, &t, &prim);
+            }
             const unsigned long long m = __ballot(vis);
             count += (uint32_t)__popcll(m & gmask);
         }
