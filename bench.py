@@ -135,6 +135,13 @@ def main():
         shadow_s = ms_shadow / 1e3 / world  # mean over ranks of the kernel's summed launch durations
         achieved = shadow_bytes / world / shadow_s / 1e9 if shadow_s > 0 else 0.0
         extend_bytes = n_prim * bray["primary"]["bytes_per_ray"] + n_cont * bray["continuation"]["bytes_per_ray"]
+        traffic = None  # HBM-side bytes per k_shadow launch, from the committed rocprofv3 PMC passes of this same workload
+        tpath = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj["workload"] == {"width": W, "height": H, "spp": spec.AntiAliasingFactor, "config": "config3"}:
+                traffic = tj["hbm_bytes_per_launch"]
         out = {
             "metric": "Mrays/s (whole node), Stanford Dragon 1080p 64spp",
             "value": rays / elapsed / 1e6,
@@ -155,7 +162,7 @@ def main():
             "kernel_ms_per_frame": {"k_extend": ms_extend / args.steps / world, "k_shadow": ms_shadow / args.steps / world,
                                     "shade_phong_other": ms_shade / args.steps / world},
             "roofline": {"bound": "hbm", "kernel": "k_shadow", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_ray": bray["shadow"]["bytes_per_ray"],
                          "k_extend_achieved": (extend_bytes / world / (ms_extend / 1e3 / world) / 1e9) if ms_extend > 0 else 0.0},
         }

@@ -1,0 +1,84 @@
+"""The other BASELINE.json configs as parity cases (reduced resolution, full scene content), the
+RMSE gate for stochastic configs, and the public GenerateImage entry point."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_against_oracle(backend, bridge, spec, scene, frac=2e-3):
+    with backend.DeviceScene(scene) as dev, bridge.OracleScene(scene) as osc:
+        acc, st = dev.render_accum(spec)
+        ref, _, ctr = osc.render(spec, mode=bridge.F32_STACK, rgba=False)
+    assert st.rays_primary == ctr["rays_primary"] == spec.Width * spec.Height * spec.AntiAliasingFactor
+    assert st.phong_hits == ctr["phong_hits"] and st.rays_shadow == ctr["rays_shadow"]
+    assert st.rays_continuation == ctr["rays_continuation"]
+    d = np.abs(acc.astype(np.float64) - ref).max(-1)
+    assert (d > 1e-3).mean() <= frac, f"{(d > 1e-3).sum()} of {d.size} pixels off, max {d.max()}"
+    return acc, st
+
+
+def test_config2_bunny_point_light(backend, bridge, scenes):
+    """config 2: Bunny stand-in (81,920 triangles), PointLight + ambient, hard (reps 1) and soft shadows."""
+    for reps in (1, 16):
+        spec, scene = scenes.config2(160, 90, 2, reps)
+        acc, st = _check_against_oracle(backend, bridge, spec, scene)
+        assert st.rays_shadow == st.phong_hits * reps and acc.max() > 0.5
+
+
+def test_config3_dragon_room(backend, bridge, scenes, gold_dir):
+    """config 3 at 160x90x2 with the full 871,210-shape scene (image-textured floor and back wall)."""
+    spec, scene = scenes.config3(160, 90, 2, 16, asset_dir=gold_dir)
+    acc, st = _check_against_oracle(backend, bridge, spec, scene)
+    assert st.rays_shadow < st.rays_shadow_reference_equivalent  # spot cones cull rays the reference would trace
+
+
+def test_config5_glass_metal_tiles(backend, bridge, scenes, rt, gold_dir):
+    """config 5 content (Bunny + Dragon stand-ins, 6 Dielectric spheres, Metal floor, 4 SpotLights), reduced
+    meshes; rendered whole and as a 2-rank tile split that must reassemble bit-exactly."""
+    spec, scene = scenes.config5(192, 108, 2, 4, asset_dir=gold_dir, nu=160, nv=120)
+    acc, st = _check_against_oracle(backend, bridge, spec, scene, frac=5e-3)
+    assert st.rays_continuation > 0.2 * st.rays_primary  # the Metal floor and the glass keep paths alive
+    abi = rt._abi
+    with backend.DeviceScene(scene) as dev:
+        parts = [dev.render_accum(spec, part=abi.partition(mode=abi.RT_PART_TILES, rank=r, world_size=2))[0] for r in range(2)]
+    assert np.array_equal(parts[0] + parts[1], acc)
+
+
+def test_rmse_against_converged_reference(backend, rt, gold_dir):
+    """Stochastic gate: config 1 at 160x95, 256 spp on the device vs the committed 4096-spp float64 oracle
+    image (different seed).  Monte-Carlo error of 256 spp dominates; a systematic error would not average out."""
+    ref = np.load(os.path.join(gold_dir, "c1_converged_160x95.npy")).astype(np.float64)
+    spec, scene = rt.ExampleRegression(160, 95, gold_dir)
+    with backend.DeviceScene(scene) as dev:
+        rmse = {}
+        for spp in (16, 256):
+            s = copy.copy(spec); s.AntiAliasingFactor = spp
+            acc, _ = dev.render_accum(s, seed=1234)
+            img = acc.astype(np.float64) / spp
+            rmse[spp] = float(np.sqrt(((np.minimum(img, 1) - np.minimum(ref, 1)) ** 2).mean()))
+        bias = float(np.abs((img - ref).mean()))
+    print("rmse", rmse, "mean bias", bias)
+    assert rmse[256] < 0.02 and rmse[256] < 0.45 * rmse[16]  # ~1/sqrt(16) = 0.25 if unbiased
+    assert bias < 2e-3
+
+
+def test_generate_image_entry_point(backend, rt, gold_dir, capsys):
+    """GenerateImage(ImageSpec, Scene) -> RGBA image, with the reference's progress messages
+    (accelerationstructures.go:28,63; raytracer.go:105)."""
+    spec, scene = rt.ExampleRegression(96, 57, gold_dir)
+    spec.AntiAliasingFactor = 4
+    img = rt.GenerateImage(spec, scene)
+    out = capsys.readouterr().out
+    assert "Building BoundingVolumeHierarchy" in out and "Finished building BoundingVolumeHierarchy" in out
+    assert "Finished ray tracing in" in out
+    assert img.Pix.shape == (57, 96, 4) and (img.Pix[..., 3] == 255).all()
+    with backend.DeviceScene(scene) as dev:
+        again, _ = dev.render(spec)
+    assert np.array_equal(img.Pix, again)
+    spec.BvhTraversalAlgorithm = 5
+    with pytest.raises(backend.RtgoError):
+        rt.GenerateImage(spec, scene)
