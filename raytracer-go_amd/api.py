@@ -80,6 +80,13 @@ class RGBAImage:
     def Height(self):
         return self.Pix.shape[0]
 
+    def save_container(self, path):
+        """Write the decoded pixels as the raw "RGBA8 <w> <h>\\n" + bytes container that the C++ mirror's
+        LoadRGBAImage (include/raytracer.hpp) reads: image.Decode is Go stdlib and has no C++ twin here."""
+        with open(path, "wb") as f:
+            f.write(f"RGBA8 {self.Width} {self.Height}\n".encode())
+            f.write(self.Pix.tobytes())
+
 
 @dataclass
 class ImageTexture:  # texture.go:23-25

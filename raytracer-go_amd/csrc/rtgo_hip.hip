@@ -80,7 +80,9 @@ struct Work {
     uint32_t* queue[2];
     uint32_t* phong_queue;
     uint32_t* vis;   // visible-repetition count per (phong hit, positional light)
-    uint32_t* counters;  // [0..D] ray-queue sizes per bounce, [D+1..2D] phong-queue sizes, [2D+2..3] shadow rays (u64)
+    uint32_t* pairs; // (hit, light) pairs whose shading term is not exactly zero: light * n_hits + hit
+    uint32_t* counters;  // [0..D] ray-queue sizes per bounce, [D+1..2D] phong-queue sizes, [2D+2..3] shadow rays (u64),
+                         // [2D+4..3D+3] pair-queue sizes per bounce
     uint32_t* overflow;  // traversal stack spill
     uint32_t overflow_stride;
 };
@@ -224,6 +226,65 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, Batch B, Work Wk, co
     if (phong) Wk.phong_queue[pat] = slot;
 }
 
+// What one visible repetition of light L adds at a PhongBlinn hit (material.go:83-119).  The light position
+// used here is the un-jittered one, so the value is the same for every repetition of a (hit, light).
+RT_DEV f3 phong_term(const DLight& L, const DMaterial& m, const f3& mc, const f3& p, const f3& nrm, const f3& d) {
+    const f3 l2p = sub3(ld3(L.pos), p);  // material.go:83-84
+    const f3 ldir = unit3(l2p);
+    const float d2 = l2p.x * l2p.x + l2p.y * l2p.y + l2p.z * l2p.z;
+    float decay = L.decay * d2;
+    if (decay <= 1.0f) decay = 1.0f;
+    const float inten = saturate(dot3(nrm, ldir));
+    const f3 diff = scale3(inten * L.intensity / decay, mk3(mc.x * L.color[0], mc.y * L.color[1], mc.z * L.color[2]));
+    const f3 h = unit3(add3(ldir, d));  // material.go:107: ray direction, not view direction
+    const float si = powf(saturate(dot3(nrm, h)), m.param);
+    const f3 spec = scale3(si * L.spec_intensity / decay, mk3(m.spec[0] * L.color[0], m.spec[1] * L.color[1], m.spec[2] * L.color[2]));
+    return mk3(min1(diff.x + spec.x), min1(diff.y + spec.y), min1(diff.z + spec.z));
+}
+
+struct PhongHit { f3 p, nrm, d, mc; DMaterial m; };
+RT_DEV PhongHit load_phong_hit(const DScene& S, const Work& Wk, uint32_t slot) {
+    const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
+    const f3 o = mk3(ro.x, ro.y, ro.z);
+    PhongHit h;
+    h.d = mk3(rdv.x, rdv.y, rdv.z);
+    const float t = ro.w;
+    const PrimData P = load_prim(S, __float_as_int(rdv.w));
+    h.m = S.materials[__float_as_uint(P.p2.y) >> 2];
+    h.p = add3(o, scale3(t, h.d));
+    h.nrm = prim_normal(P, o, h.d, t);
+    h.mc = ld3(h.m.color);
+    if (h.m.texture >= 0) {
+        float u, v;
+        texture_map(P, h.p, &u, &v);
+        h.mc = texture_color(S.textures[h.m.texture], u, v);
+    }
+    return h;
+}
+
+// One lane per (positional light, PhongBlinn hit), light-major.  A pair whose shading term is exactly
+// (0,0,0) — light behind the surface and no specular lobe towards it — adds count/reps * 0 whatever its
+// soft-shadow rays would find, so those rays are never generated: only the other pairs are queued for
+// k_shadow.  Every pair's visible-repetition count starts at 0 here.
+__global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, uint32_t n_hits, uint32_t* pair_counter) {
+    const unsigned long long idx = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    const unsigned long long total = (unsigned long long)n_hits * S.n_pos_lights;
+    bool keep = false;
+    if (idx < total) {
+        const uint32_t lp = (uint32_t)(idx / n_hits);
+        const uint32_t hit_i = (uint32_t)(idx - (unsigned long long)lp * n_hits);
+        const PhongHit h = load_phong_hit(S, Wk, Wk.phong_queue[hit_i]);
+        int q = 0;  // positional light #lp
+        for (int seen = -1; q < S.n_lights; ++q)
+            if (S.lights[q].kind != RT_LIGHT_AMBIENT && ++seen == (int)lp) break;
+        const f3 comb = phong_term(S.lights[q], h.m, h.mc, h.p, h.nrm, h.d);
+        keep = !(comb.x == 0.0f && comb.y == 0.0f && comb.z == 0.0f);
+        Wk.vis[(size_t)hit_i * S.n_pos_lights + lp] = 0u;
+    }
+    const uint32_t at = wave_push(pair_counter, keep);
+    if (keep) Wk.pairs[at] = (uint32_t)idx;
+}
+
 // One lane per (PhongBlinn hit, positional light, repetition lane).  group = lanes per (hit, light):
 // a power of two <= 64; each lane runs repetitions r, r+group, ...  The visible repetitions of a
 // (hit, light) are counted with a ballot popcount: integer, so the result has no summation order.
@@ -231,13 +292,13 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, Batch B, Work Wk, co
 // per-lane form remains for trees whose stack bound exceeds the wavefront stack in LDS.
 template <bool PACKET>
 __global__ __launch_bounds__(kBlock, 4) void k_shadow(DScene S, Batch B, Work Wk, uint32_t n_hits, int bounce,
-                                                   int group, int group_shift) {
+                                                   int group, int group_shift, const uint32_t* pair_counter) {
     __shared__ uint32_t s_stack[PACKET ? (kBlock / 64) * kPacketStackDepth : kLdsStackDepth * kBlock];
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlock;
     const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride};
     uint32_t* wave_stack = s_stack + (threadIdx.x >> 6) * kPacketStackDepth;
-    const unsigned long long total = (unsigned long long)n_hits * S.n_pos_lights * group;
+    const unsigned long long total = (unsigned long long)(*pair_counter) * group;  // written by k_phong_pairs, same stream
     const unsigned long long rounds = (total + gstride - 1) / gstride;
     const int lane = (int)__lane_id();
     const int gbase = lane & ~(group - 1);
@@ -246,12 +307,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_shadow(DScene S, Batch B, Work Wk
     for (unsigned long long it = 0; it < rounds; ++it) {
         const unsigned long long idx = it * gstride + gtid;
         const bool active = idx < total;
-        // light-major order: the lane groups of a wavefront are consecutive hits (neighbouring
+        // the pair queue is light-major: the lane groups of a wavefront are consecutive hits (neighbouring
         // pixels / samples) towards the SAME light, so all 64 shadow rays are nearly parallel
         const uint32_t r = (uint32_t)(idx & (unsigned long long)(group - 1));
-        const unsigned long long hl = idx >> group_shift;
-        const uint32_t lp = active ? (uint32_t)(hl / n_hits) : 0u;
-        const uint32_t hit_i = active ? (uint32_t)(hl - (unsigned long long)lp * n_hits) : 0u;
+        const uint32_t hl = active ? Wk.pairs[idx >> group_shift] : 0u;
+        const uint32_t lp = hl / n_hits;
+        const uint32_t hit_i = hl - lp * n_hits;
         uint32_t count = 0;
         const int iters = (B.reps + group - 1) >> group_shift;  // > 1 only when reps > 64
         for (int itn = 0; itn < iters; ++itn) {
@@ -309,20 +370,7 @@ __global__ __launch_bounds__(kBlock) void k_phong(DScene S, Batch B, Work Wk, ui
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_hits) return;
     const uint32_t slot = Wk.phong_queue[i];
-    const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
-    const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rdv.x, rdv.y, rdv.z);
-    const float t = ro.w;
-    const int prim = __float_as_int(rdv.w);
-    const PrimData P = load_prim(S, prim);
-    const DMaterial m = S.materials[__float_as_uint(P.p2.y) >> 2];
-    const f3 p = add3(o, scale3(t, d));
-    const f3 nrm = prim_normal(P, o, d, t);
-    f3 mc = ld3(m.color);
-    if (m.texture >= 0) {
-        float u, v;
-        texture_map(P, p, &u, &v);
-        mc = texture_color(S.textures[m.texture], u, v);
-    }
+    const PhongHit h = load_phong_hit(S, Wk, slot);
     f3 c = mk3(0.0f, 0.0f, 0.0f);
     int lp = 0;
     for (int q = 0; q < S.n_lights; ++q) {
@@ -331,17 +379,7 @@ __global__ __launch_bounds__(kBlock) void k_phong(DScene S, Batch B, Work Wk, ui
             const uint32_t cnt = Wk.vis[(size_t)i * S.n_pos_lights + lp];
             ++lp;
             if (cnt == 0) continue;
-            const f3 l2p = sub3(ld3(L.pos), p);  // un-jittered position, material.go:83-84
-            const f3 ldir = unit3(l2p);
-            const float d2 = l2p.x * l2p.x + l2p.y * l2p.y + l2p.z * l2p.z;
-            float decay = L.decay * d2;
-            if (decay <= 1.0f) decay = 1.0f;
-            const float inten = saturate(dot3(nrm, ldir));
-            const f3 diff = scale3(inten * L.intensity / decay, mk3(mc.x * L.color[0], mc.y * L.color[1], mc.z * L.color[2]));
-            const f3 h = unit3(add3(ldir, d));  // material.go:107: ray direction, not view direction
-            const float si = powf(saturate(dot3(nrm, h)), m.param);
-            const f3 spec = scale3(si * L.spec_intensity / decay, mk3(m.spec[0] * L.color[0], m.spec[1] * L.color[1], m.spec[2] * L.color[2]));
-            const f3 comb = mk3(min1(diff.x + spec.x), min1(diff.y + spec.y), min1(diff.z + spec.z));
+            const f3 comb = phong_term(L, h.m, h.mc, h.p, h.nrm, h.d);
             const float w = (float)cnt / (float)B.reps;  // cnt visible repetitions, each worth comb / reps
             c = add3(c, scale3(w, comb));
         } else {
@@ -436,7 +474,7 @@ namespace {
 
 void free_work(rt_scene* s) {
     Work& w = s->wk;
-    void* ptrs[] = {w.ray_o, w.ray_d, w.thr, w.rad, w.queue[0], w.queue[1], w.phong_queue, w.vis, w.counters};
+    void* ptrs[] = {w.ray_o, w.ray_d, w.thr, w.rad, w.queue[0], w.queue[1], w.phong_queue, w.vis, w.pairs, w.counters};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     uint32_t* ov = w.overflow; const uint32_t os = w.overflow_stride;
     w = Work{};
@@ -456,9 +494,10 @@ int ensure_work(rt_scene* s, int64_t paths, int depth, int lpos) {
     HIP_TRY(hipMalloc((void**)&w.queue[1], paths * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w.phong_queue, paths * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w.vis, (size_t)paths * (size_t)(lpos > 0 ? lpos : 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&w.counters, (size_t)(2 * depth + 8) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&w.pairs, (size_t)paths * (size_t)(lpos > 0 ? lpos : 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&w.counters, (size_t)(3 * depth + 8) * sizeof(uint32_t)));
     if (s->h_counters) { (void)hipHostFree(s->h_counters); s->h_counters = nullptr; }
-    HIP_TRY(hipHostMalloc((void**)&s->h_counters, (size_t)(2 * depth + 8) * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void**)&s->h_counters, (size_t)(3 * depth + 8) * sizeof(uint32_t)));
     s->wk_paths = paths; s->wk_depth = depth; s->wk_lpos = lpos;
     return RT_OK;
 }
@@ -734,6 +773,10 @@ int rt_render_accum_device(rt_scene* s, const rt_image_spec* spec, const rt_part
         int64_t max_paths = part.max_paths_per_batch > 0 ? part.max_paths_per_batch : kDefaultMaxPaths;
         if (max_paths < (int64_t)tile * tile) max_paths = (int64_t)tile * tile;
         if (max_paths > ((int64_t)1 << 30)) max_paths = (int64_t)1 << 30;
+        // a (hit, light) pair travels as one u32: light * hits + hit
+        const int64_t pair_cap = (((int64_t)1 << 32) - 1) / std::max(1, s->d.n_pos_lights);
+        if (pair_cap < (int64_t)tile * tile) return fail(RT_ERR_LIMIT, "too many positional lights for one tile of paths; use a smaller tile_size");
+        if (max_paths > pair_cap) max_paths = pair_cap;
         const int ns_max = (int)std::min<long long>(sB - sA, std::min<long long>(64, max_paths / ((long long)tile * tile)));
         const long long pix_per_batch = std::max<long long>(1, max_paths / ns_max / ((long long)tile * tile)) * tile * tile;
         rc = ensure_work(s, (int64_t)std::min<long long>(pix_per_batch, n_local_pixels) * ns_max, D, s->d.n_pos_lights);
@@ -755,7 +798,7 @@ int rt_render_accum_device(rt_scene* s, const rt_image_spec* spec, const rt_part
             st.ms_shadow += a; st.ms_shade += b;
             pend_shadow = false;
         };
-        const size_t n_ctr = (size_t)(2 * D + 8);
+        const size_t n_ctr = (size_t)(3 * D + 8);
         for (int s0 = sA; s0 < sB; s0 += ns_max) {
             const int ns = std::min(ns_max, sB - s0);
             for (long long lp0 = 0; lp0 < n_local_pixels; lp0 += pix_per_batch) {
@@ -797,18 +840,23 @@ int rt_render_accum_device(rt_scene* s, const rt_image_spec* spec, const rt_part
                     if (np > 0) {
                         st.phong_hits += np;
                         st.rays_shadow_reference_equivalent += (uint64_t)np * s->d.n_pos_lights * reps;
-                        if (timed) HIP_TRY(hipEventRecord(ev[3], stream));
-                        if (s->d.n_pos_lights > 0 && reps > 0) {
-                            const unsigned long long lanes = (unsigned long long)np * s->d.n_pos_lights * group;
-                            // The per-lane form measured faster on config 3 (2.71 s vs 3.08 s per frame): the packet form
-                            // serialises the union of the nodes its 64 rays touch and becomes scalar-ALU bound.
-                            static const bool use_packet = std::getenv("RTGO_SHADOW_PACKET") != nullptr;  // A/B switch
-                            if (s->info.stack_bound <= kPacketStackDepth && use_packet)
-                                hipLaunchKernelGGL(k_shadow<true>, dim3(grid_for(lanes)), dim3(kBlock), 0, stream, s->d, B, wk, np, b, group, group_shift);
-                            else
-                                hipLaunchKernelGGL(k_shadow<false>, dim3(grid_for(lanes)), dim3(kBlock), 0, stream, s->d, B, wk, np, b, group, group_shift);
-                        } else if (s->d.n_pos_lights > 0) {
-                            HIP_TRY(hipMemsetAsync(wk.vis, 0, (size_t)np * s->d.n_pos_lights * sizeof(uint32_t), stream));
+                        if (s->d.n_pos_lights == 0 && timed) HIP_TRY(hipEventRecord(ev[3], stream));
+                        if (s->d.n_pos_lights > 0) {
+                            const unsigned long long n_pairs = (unsigned long long)np * s->d.n_pos_lights;
+                            uint32_t* pair_counter = wk.counters + 2 * D + 4 + b;
+                            hipLaunchKernelGGL(k_phong_pairs, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                                               s->d, wk, np, pair_counter);
+                            if (timed) HIP_TRY(hipEventRecord(ev[3], stream));  // ms_shadow brackets k_shadow alone
+                            if (reps > 0) {
+                                // The per-lane form measured faster on config 3 (2.71 s vs 3.08 s per frame): the packet form
+                                // serialises the union of the nodes its 64 rays touch and becomes scalar-ALU bound.
+                                static const bool use_packet = std::getenv("RTGO_SHADOW_PACKET") != nullptr;  // A/B switch
+                                const int grid = grid_for(n_pairs * group);  // upper bound; the kernel reads the real pair count
+                                if (s->info.stack_bound <= kPacketStackDepth && use_packet)
+                                    hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), 0, stream, s->d, B, wk, np, b, group, group_shift, pair_counter);
+                                else
+                                    hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kBlock), 0, stream, s->d, B, wk, np, b, group, group_shift, pair_counter);
+                            }
                         }
                         if (timed) HIP_TRY(hipEventRecord(ev[4], stream));
                         hipLaunchKernelGGL(k_phong, dim3((np + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, B, wk, np);

@@ -269,9 +269,18 @@ def test_soft_shadow_repetition_counts(backend, bridge, rt):
             spec = rt.ImageSpec(64, 40, 2, 4, reps, 1, 0)
             acc, st = dev.render_accum(spec)
             ref, _, ctr = osc.render(spec, mode=bridge.F32_STACK, rgba=False)
-            assert st.rays_shadow == ctr["rays_shadow"] == st.phong_hits * 2 * reps
+            # pairs whose shading term is exactly zero (light behind the surface) generate no shadow rays
+            assert st.rays_shadow == ctr["rays_shadow"] and 0 < st.rays_shadow < st.phong_hits * 2 * reps
+            assert st.rays_shadow % reps == 0 and st.rays_shadow_reference_equivalent == st.phong_hits * 2 * reps
             d = np.abs(acc.astype(np.float64) - ref).max()
             assert d < 1e-4, (reps, d)
+        # ... and leaving them out changes nothing: the reference-faithful fp64 mode traces every one of them
+        spec = rt.ImageSpec(64, 40, 2, 4, 16, 1, 0)
+        acc, st = dev.render_accum(spec)
+        ref64, _, ctr64 = osc.render(spec, mode=bridge.F64_DIJKSTRA, rgba=False)
+        assert ctr64["rays_shadow"] == st.rays_shadow_reference_equivalent > st.rays_shadow
+        close = np.abs(acc.astype(np.float64) - ref64).max(axis=-1) < 1e-3
+        assert close.mean() > 0.995, close.mean()
 
 
 def test_deep_tree_uses_stack_spill(backend, bridge, rt):
