@@ -170,6 +170,7 @@ struct Node {
     // F32_STACK helpers (filled after the build)
     float fmin[3], fmax[3];
     int count = 0;  // shapes in the subtree
+    Node* slot[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // device block rooted here
 };
 
 struct Scene {
@@ -338,6 +339,73 @@ inline Node* effective(Node* n) {
         n = only;
     }
     return n;
+}
+
+// The device flattener's block of an effective inner node x (csrc/octree.cpp block_slots), restated:
+// slot o starts as the chain-skipped child of octant o; then, while some inner child (more than
+// leaf_size shapes) can be replaced by its own children within 8 slots, the one with the largest box
+// area (first in slot order on ties) is, and its children take free slots by greedy matching on
+// score = sum over axes of (+/-)(child centre - block centre), + where the slot's octant bit is set
+// (largest first; ties to the lower child octant, then the lower slot).
+inline double node_area(const Node* n) {
+    const double dx = n->pmax.x - n->pmin.x, dy = n->pmax.y - n->pmin.y, dz = n->pmax.z - n->pmin.z;
+    return 2.0 * ((dx * dy + dy * dz) + dz * dx);
+}
+void build_block(Node* x, int leaf_size, bool collapse) {
+    int n = 0;
+    for (int o = 0; o < 8; ++o) {
+        x->slot[o] = x->children[o] ? effective(x->children[o]) : nullptr;
+        if (x->slot[o]) ++n;
+    }
+    const V3<double> m{(x->pmin.x + x->pmax.x) * 0.5, (x->pmin.y + x->pmax.y) * 0.5, (x->pmin.z + x->pmax.z) * 0.5};
+    while (collapse) {
+        int pick = -1, pick_k = 0;
+        double pick_area = 0;
+        for (int s = 0; s < 8; ++s) {
+            Node* e = x->slot[s];
+            if (!e || e->count <= leaf_size) continue;
+            int k = 0;
+            for (Node* c : e->children) if (c) ++k;
+            if (n - 1 + k > 8) continue;
+            const double a = node_area(e);
+            if (pick < 0 || a > pick_area) { pick = s; pick_area = a; pick_k = k; }
+        }
+        if (pick < 0) break;
+        Node* e = x->slot[pick];
+        x->slot[pick] = nullptr;
+        std::vector<Node*> kids;
+        for (Node* c : e->children) if (c) kids.push_back(effective(c));
+        std::vector<char> placed(kids.size(), 0);
+        for (size_t round = 0; round < kids.size(); ++round) {
+            int bi = -1, bs = -1;
+            double bscore = 0;
+            for (size_t i = 0; i < kids.size(); ++i) {
+                if (placed[i]) continue;
+                const Node* c = kids[i];
+                const V3<double> ctr{(c->pmin.x + c->pmax.x) * 0.5, (c->pmin.y + c->pmax.y) * 0.5, (c->pmin.z + c->pmax.z) * 0.5};
+                for (int sl = 0; sl < 8; ++sl) {
+                    if (x->slot[sl]) continue;
+                    const double sx = (sl & 1) ? 1.0 : -1.0, sy = (sl & 2) ? 1.0 : -1.0, sz = (sl & 4) ? 1.0 : -1.0;
+                    const double score = (sx * (ctr.x - m.x) + sy * (ctr.y - m.y)) + sz * (ctr.z - m.z);
+                    if (bi < 0 || score > bscore) { bi = (int)i; bs = sl; bscore = score; }
+                }
+            }
+            x->slot[bs] = kids[(size_t)bi];
+            placed[(size_t)bi] = 1;
+        }
+        n += pick_k - 1;
+    }
+}
+void build_blocks(Node* root, int leaf_size) {
+    const bool collapse = std::getenv("RTGO_NO_COLLAPSE") == nullptr;
+    std::vector<Node*> todo{effective(root)};
+    while (!todo.empty()) {
+        Node* x = todo.back();
+        todo.pop_back();
+        if (x->leaf || x->count <= leaf_size) continue;
+        build_block(x, leaf_size, collapse);
+        for (Node* e : x->slot) if (e && e->count > leaf_size) todo.push_back(e);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -556,7 +624,7 @@ bool trace_stack_f32(const Scene& sc, const Ray<float>& r, float tmin, float tma
     Node fake;  // a root that is itself one leaf gets a synthetic one-child parent, as in the device flattener
     if (root->count <= leaf_size) {
         if (root->count == 0) { out = hr; return false; }
-        fake.leaf = false; fake.has_children = true; fake.children[0] = root;
+        fake.leaf = false; fake.has_children = true; fake.slot[0] = root;
         root = &fake;
     }
     std::vector<int> group;
@@ -569,10 +637,8 @@ bool trace_stack_f32(const Scene& sc, const Ray<float>& r, float tmin, float tma
         // pass 1: every present child's box against the best t at node entry, in ray order
         const float entry_best = hr.t;
         for (int k = 0; k < 8; ++k) {
-            Node* c = cur->children[k ^ sr.sign];
-            if (!c) continue;
-            // box of the slot is the box of the un-collapsed child (identical after refit)
-            Node* e = effective(c);
+            Node* e = cur->slot[k ^ sr.sign];  // chain-skipped already: same box as the un-collapsed child after the refit
+            if (!e) continue;
             if (!slab_f32(sr, e->fmin, e->fmax, t0, entry_best)) continue;
             if (e->count <= leaf_size) leaves[nl++] = e; else pending[np++] = e;
         }
@@ -983,11 +1049,15 @@ orc_scene* orc_scene_create(const rt_scene_desc* d) {
     Builder b{sc};
     b.build();
     fill_f32_boxes(sc.root);
+    build_blocks(sc.root, sc.leaf_size);
     return o;
 }
 void orc_scene_destroy(orc_scene* s) { delete s; }
 // F32_STACK only: shapes per leaf of the device tree being mirrored (RTGO_LEAF_SIZE, default 4)
-void orc_set_leaf_size(orc_scene* s, int leaf_size) { s->sc.leaf_size = leaf_size; }
+void orc_set_leaf_size(orc_scene* s, int leaf_size) {
+    s->sc.leaf_size = leaf_size < 1 ? 1 : leaf_size;
+    build_blocks(s->sc.root, s->sc.leaf_size);
+}
 
 // out[0] = pointer-tree node count, out[1] = inner nodes (non-leaf, after prune), out[2] = max depth
 void orc_tree_info(const orc_scene* s, int64_t* out) {

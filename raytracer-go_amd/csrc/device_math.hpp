@@ -198,20 +198,26 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
                 }
             }
         }
-        while (leaf_mask) {
-            const int k = __ffs((int)leaf_mask) - 1;
-            leaf_mask &= leaf_mask - 1u;
-            uint32_t leaf = ref[0];
+        // One flat loop over the shapes of all hit leaves (leaves in ray order, a leaf's shapes in stored
+        // order): a wavefront iterates max-over-lanes(total shapes) times, not once per (leaf, shape) pair.
+        uint32_t pnext = 0, pleft = 0;
+        for (;;) {
+            if (pleft == 0) {
+                if (!leaf_mask) break;
+                const int k = __ffs((int)leaf_mask) - 1;
+                leaf_mask &= leaf_mask - 1u;
+                uint32_t leaf = ref[0];
 #pragma unroll
-            for (int q = 1; q < 8; ++q) leaf = (k == q) ? ref[q] : leaf;
-            const uint32_t pfirst = leaf >> 8, pcount = leaf & 0xffu;  // the leaf's shapes, contiguous
-            for (uint32_t c = 0; c < pcount; ++c) {
-                const uint32_t prim = pfirst + c;
-                const float t = prim_hit(S, prim, o, d, tmin, best);
-                if (ANY) {
-                    if (t > 0.0f && t <= best) { *t_out = t; *prim_out = (int)prim; return true; }
-                } else if (t > 0.0f && t < best) { best = t; best_prim = (int)prim; }
+                for (int q = 1; q < 8; ++q) leaf = (k == q) ? ref[q] : leaf;
+                pnext = leaf >> 8;  // the leaf's shapes are contiguous
+                pleft = leaf & 0xffu;
             }
+            const uint32_t prim = pnext++;
+            --pleft;
+            const float t = prim_hit(S, prim, o, d, tmin, best);
+            if (ANY) {
+                if (t > 0.0f && t <= best) { *t_out = t; *prim_out = (int)prim; return true; }
+            } else if (t > 0.0f && t < best) { best = t; best_prim = (int)prim; }
         }
         if (inner_mask) {
             // far-to-near pushes of everything but the nearest, which is entered directly
