@@ -454,6 +454,34 @@ template <class R> inline Hit<R> triangle_hit(const Shape<R>& tr, int idx, const
     if (t < tmin || t > tmax) return {(R)-1, {}, {}, -1};
     return {t, point_at(r, t), unit(cross(e1, e2)), idx};
 }
+// Device shadow-ray form (device_math.hpp triangle_occludes): fused, division-free; t only on a hit.
+inline float dotf(const V3<float>& a, const V3<float>& b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+inline V3<float> crossf(const V3<float>& a, const V3<float>& b) {
+    return {fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
+}
+inline float flip(float x, uint32_t sb) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    u ^= sb;
+    std::memcpy(&x, &u, 4);
+    return x;
+}
+inline Hit<float> triangle_occludes_f32(const Shape<float>& tr, int idx, const Ray<float>& r, float tmin, float tmax) {
+    const V3<float> e1 = sub(tr.b, tr.a), e2 = sub(tr.c, tr.a);
+    const V3<float> pvec = crossf(r.d, e2);
+    const float det = dotf(e1, pvec);
+    const V3<float> tvec = sub(r.p, tr.a);
+    const V3<float> qvec = crossf(tvec, e1);
+    uint32_t sb;
+    std::memcpy(&sb, &det, 4);
+    sb &= 0x80000000u;
+    const float ad = flip(det, sb);
+    const float us = flip(dotf(tvec, pvec), sb), vs = flip(dotf(r.d, qvec), sb), ts = flip(dotf(e2, qvec), sb);
+    const bool hit = ad > 0.0f && !(tr.single_sided && sb) && us >= 0.0f && vs >= 0.0f && us + vs <= ad &&
+                     ts >= tmin * ad && ts <= tmax * ad;
+    if (!hit) return {-1.0f, {}, {}, -1};
+    return {ts / ad, {}, {}, idx};
+}
 template <class R> inline Hit<R> shape_hit(const Tables<R>& T, int idx, const Ray<R>& r, R tmin, R tmax) {
     const Shape<R>& s = T.shapes[idx];
     return s.kind == RT_SHAPE_SPHERE ? sphere_hit(s, idx, r, tmin, tmax) : triangle_hit(s, idx, r, tmin, tmax);
@@ -648,7 +676,9 @@ bool trace_stack_f32(const Scene& sc, const Ray<float>& r, float tmin, float tma
             subtree_shapes(leaves[q], &group);
             for (int shape : group) {
                 if (tc) tc->leaf++;
-                const Hit<float> sh = shape_hit(sc.t32, shape, r, tmin, hr.t);
+                const Hit<float> sh = (any_hit && sc.t32.shapes[(size_t)shape].kind == RT_SHAPE_TRIANGLE)
+                                          ? triangle_occludes_f32(sc.t32.shapes[(size_t)shape], shape, r, tmin, hr.t)
+                                          : shape_hit(sc.t32, shape, r, tmin, hr.t);
                 if (any_hit) {
                     if (sh.t > 0.0f && sh.t <= hr.t) { out = sh; return true; }
                 } else if (sh.t > 0.0f && sh.t < hr.t) { hr = sh; found = true; }

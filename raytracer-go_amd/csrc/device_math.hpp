@@ -114,13 +114,44 @@ RT_DEV float triangle_hit(f3 A, f3 B, f3 C, bool single_sided, f3 o, f3 d, float
     if (t < tmin || t > tmax) return -1.0f;
     return t;
 }
+// Shadow rays only need "is there a hit with tmin <= t <= tmax": the same Moller-Trumbore quantities,
+// but fused (explicit fmaf) and without the division — u, v, t are compared against |det| instead of
+// being scaled by 1/det, and t is divided out only for an actual hit.  The outcome can differ from
+// triangle_hit's only for a ray within a rounding error of an edge or of tmin/tmax; nearest-hit rays
+// (whose t, shape and barycentrics are visible in the image) keep the reference's expression order.
+RT_DEV float dotf(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+RT_DEV f3 crossf(f3 a, f3 b) {
+    return mk3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+RT_DEV float triangle_occludes(f3 A, f3 B, f3 C, bool single_sided, f3 o, f3 d, float tmin, float tmax) {
+    const f3 e1 = sub3(B, A), e2 = sub3(C, A);
+    const f3 pvec = crossf(d, e2);
+    const float det = dotf(e1, pvec);
+    const f3 tvec = sub3(o, A);
+    const f3 qvec = crossf(tvec, e1);
+    const uint32_t sb = __float_as_uint(det) & 0x80000000u;  // move det's sign onto u, v, t
+    const float ad = __uint_as_float(__float_as_uint(det) ^ sb);
+    const float us = __uint_as_float(__float_as_uint(dotf(tvec, pvec)) ^ sb);
+    const float vs = __uint_as_float(__float_as_uint(dotf(d, qvec)) ^ sb);
+    const float ts = __uint_as_float(__float_as_uint(dotf(e2, qvec)) ^ sb);
+    const bool hit = ad > 0.0f && !(single_sided && sb) && us >= 0.0f && vs >= 0.0f && us + vs <= ad &&
+                     ts >= tmin * ad && ts <= tmax * ad;
+    return hit ? ts / ad : -1.0f;
+}
+template <bool ANY>
 RT_DEV float prim_hit(const DScene& S, uint32_t prim, f3 o, f3 d, float tmin, float tmax) {
     // all three quads are fetched together (a sphere ignores p1): one memory latency per shape
-    const float4 p0 = S.prims[3 * (size_t)prim];
-    const float4 p1 = S.prims[3 * (size_t)prim + 1];
-    const float4 p2 = S.prims[3 * (size_t)prim + 2];
+    float4 p0 = S.prims[3 * (size_t)prim];
+    float4 p1 = S.prims[3 * (size_t)prim + 1];
+    float4 p2 = S.prims[3 * (size_t)prim + 2];
+    // keeps the compiler from sinking the p1 / p2 loads below the triangle-or-sphere branch, which would
+    // make them a second, dependent memory round trip per shape
+    asm volatile("" : "+v"(p0.x), "+v"(p1.x), "+v"(p2.x), "+v"(p2.y));
     const uint32_t bits = __float_as_uint(p2.y);
     if (bits & kPrimTriangle) {
+        if (ANY)
+            return triangle_occludes(mk3(p0.x, p0.y, p0.z), mk3(p0.w, p1.x, p1.y), mk3(p1.z, p1.w, p2.x),
+                                     (bits & kPrimSingleSided) != 0, o, d, tmin, tmax);
         return triangle_hit(mk3(p0.x, p0.y, p0.z), mk3(p0.w, p1.x, p1.y), mk3(p1.z, p1.w, p2.x),
                             (bits & kPrimSingleSided) != 0, o, d, tmin, tmax);
     }
@@ -174,29 +205,27 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
             rb[k] = S.recs[2 * idx + 1];
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 8; ++k) {  // no branch per slot: an absent slot's result is masked out
             const uint32_t oct = (uint32_t)k ^ sign;
-            ref[k] = 0;
-            if ((present >> oct) & 1u) {
-                const float4 a = ra[k], b = rb[k];
-                float tn = 0.0f, tf = entry_best;
-                {
-                    const float lo = fmaf(a.x, inv.x, -oi.x), hi = fmaf(a.w, inv.x, -oi.x);
-                    tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
-                }
-                {
-                    const float lo = fmaf(a.y, inv.y, -oi.y), hi = fmaf(b.x, inv.y, -oi.y);
-                    tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
-                }
-                {
-                    const float lo = fmaf(a.z, inv.z, -oi.z), hi = fmaf(b.y, inv.z, -oi.z);
-                    tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
-                }
-                if (tn <= tf) {
-                    ref[k] = __float_as_uint(b.z);
-                    if (__float_as_uint(b.w) & kLeaf) leaf_mask |= 1u << k; else inner_mask |= 1u << k;
-                }
+            const float4 a = ra[k], b = rb[k];
+            float tn = 0.0f, tf = entry_best;
+            {
+                const float lo = fmaf(a.x, inv.x, -oi.x), hi = fmaf(a.w, inv.x, -oi.x);
+                tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
             }
+            {
+                const float lo = fmaf(a.y, inv.y, -oi.y), hi = fmaf(b.x, inv.y, -oi.y);
+                tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+            }
+            {
+                const float lo = fmaf(a.z, inv.z, -oi.z), hi = fmaf(b.y, inv.z, -oi.z);
+                tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+            }
+            const uint32_t hit = (((present >> oct) & 1u) != 0u && tn <= tf) ? (1u << k) : 0u;
+            ref[k] = __float_as_uint(b.z);
+            const bool is_leaf = (__float_as_uint(b.w) & kLeaf) != 0u;
+            leaf_mask |= is_leaf ? hit : 0u;
+            inner_mask |= is_leaf ? 0u : hit;
         }
         // One flat loop over the shapes of all hit leaves (leaves in ray order, a leaf's shapes in stored
         // order): a wavefront iterates max-over-lanes(total shapes) times, not once per (leaf, shape) pair.
@@ -214,7 +243,7 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
             }
             const uint32_t prim = pnext++;
             --pleft;
-            const float t = prim_hit(S, prim, o, d, tmin, best);
+            const float t = prim_hit<ANY>(S, prim, o, d, tmin, best);
             if (ANY) {
                 if (t > 0.0f && t <= best) { *t_out = t; *prim_out = (int)prim; return true; }
             } else if (t > 0.0f && t < best) { best = t; best_prim = (int)prim; }
@@ -299,7 +328,7 @@ RT_DEV bool packet_occluded(const DScene& S, uint32_t* wave_stack, bool alive, f
                 if (hit && !occluded) {
                     float t;
                     if (bits & kPrimTriangle)
-                        t = triangle_hit(mk3(p0[0], p0[1], p0[2]), mk3(p0[3], p1[0], p1[1]), mk3(p1[2], p1[3], p2[0]),
+                        t = triangle_occludes(mk3(p0[0], p0[1], p0[2]), mk3(p0[3], p1[0], p1[1]), mk3(p1[2], p1[3], p2[0]),
                                          (bits & kPrimSingleSided) != 0, o, d, tmin, tmax);
                     else
                         t = sphere_hit(make_float4(p0[0], p0[1], p0[2], p0[3]), o, d, tmin, tmax);
