@@ -250,9 +250,20 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
         }
         if (inner_mask) {
             // far-to-near pushes of everything but the nearest, which is entered directly
+            const uint32_t rest = inner_mask & (inner_mask - 1u);
+            if (sp + 7 <= kLdsStackDepth) {
+                // common case, no branch per entry: every slot stores at the current top and the top only
+                // moves for the slots that were hit (the stores beyond it are overwritten or never read)
 #pragma unroll
-            for (int k = 7; k >= 1; --k)
-                if (((inner_mask >> k) & 1u) && (inner_mask & ((1u << k) - 1u))) st.put(sp++, ref[k]);
+                for (int k = 7; k >= 1; --k) {
+                    st.lds[sp * st.lds_stride] = ref[k];
+                    sp += (int)((rest >> k) & 1u);
+                }
+            } else {
+#pragma unroll
+                for (int k = 7; k >= 1; --k)
+                    if ((rest >> k) & 1u) st.put(sp++, ref[k]);
+            }
 #pragma unroll
             for (int k = 7; k >= 0; --k) cur = ((inner_mask >> k) & 1u) ? ref[k] : cur;
             continue;
