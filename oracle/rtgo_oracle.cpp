@@ -795,11 +795,21 @@ template <class R> void texture_map(const Shape<R>& s, const V3<R>& point, R& u,
 // ------------------------------------------------------------------------------------
 // Materials (material.go:34-172)
 // ------------------------------------------------------------------------------------
+// material.go:134-143.  Randomness spec: one Philox block per call; try 0 uses its first
+// three words, every further try three words of the xorshift128 stream seeded with the block's four.
+inline uint32_t xorshift128(U4& s) {
+    const uint32_t t = s.v[0] ^ (s.v[0] << 11);
+    s.v[0] = s.v[1]; s.v[1] = s.v[2]; s.v[2] = s.v[3];
+    s.v[3] = s.v[3] ^ (s.v[3] >> 19) ^ t ^ (t >> 8);
+    return s.v[3];
+}
 template <class R> inline V3<R> random_in_unit_sphere(const RngKey& k, uint32_t bounce, uint32_t purpose, uint32_t sub_) {
-    for (int tr = 0; tr < kMaxTries; ++tr) {  // material.go:134-143
-        const U4 w = draw(k, bounce, purpose, sub_, tr);
-        const V3<R> p = sub(scale((R)2, V3<R>{u01<R>(w.v[0]), u01<R>(w.v[1]), u01<R>(w.v[2])}), V3<R>{1, 1, 1});
+    U4 s = draw(k, bounce, purpose, sub_, 0);
+    uint32_t w0 = s.v[0], w1 = s.v[1], w2 = s.v[2];
+    for (int tr = 0; tr < kMaxTries; ++tr) {
+        const V3<R> p = sub(scale((R)2, V3<R>{u01<R>(w0), u01<R>(w1), u01<R>(w2)}), V3<R>{1, 1, 1});
         if (p.x * p.x + p.y * p.y + p.z * p.z < (R)1.0) return p;
+        w0 = xorshift128(s); w1 = xorshift128(s); w2 = xorshift128(s);
     }
     return {0, 0, 0};
 }

@@ -53,12 +53,23 @@ RT_DEV u4 draw(const RngKey& k, uint32_t bounce, uint32_t purpose, uint32_t sub,
 }
 RT_DEV float u01(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
 
-// randomInUnitSphere, material.go:134-143 (rejection loop capped at kMaxTries)
+// randomInUnitSphere, material.go:134-143 (rejection loop capped at kMaxTries).  ONE Philox block per
+// call: try 0 takes its first three words; further tries take three words each from a xorshift128
+// stream seeded with the block's four words.  (A Philox block per try cost the 64 lanes of a wavefront
+// ~5.7 blocks — the slowest lane's try count — and was 16 % of the shadow kernel's instructions.)
+RT_DEV uint32_t xorshift128(u4* s) {
+    const uint32_t t = s->x ^ (s->x << 11);
+    s->x = s->y; s->y = s->z; s->z = s->w;
+    s->w = s->w ^ (s->w >> 19) ^ t ^ (t >> 8);
+    return s->w;
+}
 RT_DEV f3 random_in_unit_sphere(const RngKey& k, uint32_t bounce, uint32_t purpose, uint32_t sub) {
+    u4 s = draw(k, bounce, purpose, sub, 0u);
+    uint32_t a = s.x, b = s.y, c = s.z;
     for (int tr = 0; tr < kMaxTries; ++tr) {
-        const u4 w = draw(k, bounce, purpose, sub, (uint32_t)tr);
-        const f3 p = sub3(scale3(2.0f, mk3(u01(w.x), u01(w.y), u01(w.z))), mk3(1.0f, 1.0f, 1.0f));
+        const f3 p = sub3(scale3(2.0f, mk3(u01(a), u01(b), u01(c))), mk3(1.0f, 1.0f, 1.0f));
         if (p.x * p.x + p.y * p.y + p.z * p.z < 1.0f) return p;
+        a = xorshift128(&s); b = xorshift128(&s); c = xorshift128(&s);
     }
     return mk3(0.0f, 0.0f, 0.0f);
 }
