@@ -169,16 +169,40 @@ RT_DEV float prim_hit(const DScene& S, uint32_t prim, f3 o, f3 d, float tmin, fl
     return sphere_hit(p0, o, d, tmin, tmax);
 }
 
+// ---- optional loop instrumentation (make prof -> librtgo_prof.so, scripts/prof_loops.py) ----
+#ifdef RTGO_PROF
+__device__ unsigned long long g_prof[8];  // [2i] = times a wavefront passed point i, [2i+1] = lanes active there
+#define RT_PROF_POINT(i)                                                          \
+    do {                                                                          \
+        const unsigned long long m_ = __ballot(true);                             \
+        if ((int)__lane_id() == __ffsll((long long)m_) - 1) {                     \
+            atomicAdd(&g_prof[2 * (i)], 1ull);                                    \
+            atomicAdd(&g_prof[2 * (i) + 1], (unsigned long long)__popcll(m_));    \
+        }                                                                         \
+    } while (0)
+#else
+#define RT_PROF_POINT(i)
+#endif
+
 // ---- ordered stack traversal --------------------------------------------------------------
 // Replaces bvh.trace (accelerationstructures.go:81-124): same nearest hit, found with a stack
-// instead of a heap.  Per node: (1) every present child's box is slab-tested against the best t
-// at node entry, in ray order k = 0..7, octant = k ^ sign mask; (2) hit leaf children are
-// intersected in that order, a hit is accepted iff t > 0 && t < best (strict: first found wins
-// ties, as :101); (3) hit inner children are pushed far-to-near and the nearest is entered.
+// instead of a heap.  Per block: (1) every present child's box is slab-tested against the best t
+// known at block entry, in ray order k = 0..7, slot = k ^ sign mask; (2) hit leaf children are queued
+// in that order; (3) hit inner children are pushed far-to-near and the nearest is entered.
+// The queued leaves' shapes are intersected in queue order, a hit accepted iff t > 0 && t < best
+// (strict: first found wins ties, as :101) — but not right away: a wavefront runs its shape loop only
+// once enough of its lanes hold queued leaves (kFlushLanes, or as many as are still walking), because
+// a shape loop entered for the few lanes that hit a leaf in the current block ran at 16 % lane
+// utilisation and was half of the kernel's instructions.  Holding a leaf back cannot change the
+// result: the shapes are still tested in the same order, and a box that a smaller `best` would have
+// culled holds no hit below that `best`.
 // ANY = shadow-ray form of doesReachLight (light.go:141-160): first accepted t <= tmax ends it.
 constexpr int kLdsStackDepth = 24;
+constexpr int kPendCap = 8;     // leaves a lane can hold back (one block visit adds at most 8)
+constexpr int kFlushLanes = 32; // run the shape loop when this many lanes hold leaves
+constexpr int kLdsPerLane = kLdsStackDepth + kPendCap + 1;  // +1: the branch-free append stores one past the last
 struct TraceStack {
-    uint32_t* lds;        // &s_stack[threadIdx.x], entries kBlock apart
+    uint32_t* lds;        // &s_stack[threadIdx.x], entries kBlock apart: [0, kLdsStackDepth) stack, then the leaf queue
     uint32_t* overflow;   // &overflow[global thread], entries `stride` apart (worst-case depth)
     uint32_t lds_stride, stride;
     RT_DEV void put(int sp, uint32_t v) const {
@@ -198,89 +222,121 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
     int best_prim = -1;
     uint32_t cur = S.root_ref;
     int sp = 0;
-    for (;;) {
-        const uint32_t first = cur >> 8, present = cur & 0xffu;
-        uint32_t ref[8];
-        uint32_t leaf_mask = 0, inner_mask = 0;  // bit k = ray-order position
-        const float entry_best = best;
-        // All child records are fetched before any is tested, with no branch around the loads (an
-        // absent child re-reads the block's first record): one memory latency per node instead of one
-        // per present child.
-        float4 ra[8], rb[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t oct = (uint32_t)k ^ sign;
-            const uint32_t below = (uint32_t)__popc(present & ((1u << oct) - 1u));
-            const size_t idx = (size_t)first + (((present >> oct) & 1u) ? below : 0u);
-            ra[k] = S.recs[2 * idx];
-            rb[k] = S.recs[2 * idx + 1];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {  // no branch per slot: an absent slot's result is masked out
-            const uint32_t oct = (uint32_t)k ^ sign;
-            const float4 a = ra[k], b = rb[k];
-            float tn = 0.0f, tf = entry_best;
-            {
-                const float lo = fmaf(a.x, inv.x, -oi.x), hi = fmaf(a.w, inv.x, -oi.x);
-                tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
-            }
-            {
-                const float lo = fmaf(a.y, inv.y, -oi.y), hi = fmaf(b.x, inv.y, -oi.y);
-                tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
-            }
-            {
-                const float lo = fmaf(a.z, inv.z, -oi.z), hi = fmaf(b.y, inv.z, -oi.z);
-                tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
-            }
-            const uint32_t hit = (((present >> oct) & 1u) != 0u && tn <= tf) ? (1u << k) : 0u;
-            ref[k] = __float_as_uint(b.z);
-            const bool is_leaf = (__float_as_uint(b.w) & kLeaf) != 0u;
-            leaf_mask |= is_leaf ? hit : 0u;
-            inner_mask |= is_leaf ? 0u : hit;
-        }
-        // One flat loop over the shapes of all hit leaves (leaves in ray order, a leaf's shapes in stored
-        // order): a wavefront iterates max-over-lanes(total shapes) times, not once per (leaf, shape) pair.
-        uint32_t pnext = 0, pleft = 0;
+    bool walking = true;   // has a block to visit
+    bool occluded = false; // ANY: an accepted hit was found
+    uint32_t npend = 0;    // queued leaves
+    uint32_t* const pend = st.lds + kLdsStackDepth * st.lds_stride;
+
+    // the shape loop: one flat loop over the shapes of all queued leaves, in queue order
+    auto flush = [&]() {
+        uint32_t qhead = 0, pnext = 0, pleft = 0;
         for (;;) {
             if (pleft == 0) {
-                if (!leaf_mask) break;
-                const int k = __ffs((int)leaf_mask) - 1;
-                leaf_mask &= leaf_mask - 1u;
-                uint32_t leaf = ref[0];
-#pragma unroll
-                for (int q = 1; q < 8; ++q) leaf = (k == q) ? ref[q] : leaf;
+                if (qhead == npend) break;
+                const uint32_t leaf = pend[qhead * st.lds_stride];
+                ++qhead;
                 pnext = leaf >> 8;  // the leaf's shapes are contiguous
                 pleft = leaf & 0xffu;
             }
+            RT_PROF_POINT(1);  // shape tests
             const uint32_t prim = pnext++;
             --pleft;
             const float t = prim_hit<ANY>(S, prim, o, d, tmin, best);
             if (ANY) {
-                if (t > 0.0f && t <= best) { *t_out = t; *prim_out = (int)prim; return true; }
+                if (t > 0.0f && t <= best) { best = t; best_prim = (int)prim; occluded = true; break; }
             } else if (t > 0.0f && t < best) { best = t; best_prim = (int)prim; }
         }
-        if (inner_mask) {
-            // far-to-near pushes of everything but the nearest, which is entered directly
-            const uint32_t rest = inner_mask & (inner_mask - 1u);
-            if (sp + 7 <= kLdsStackDepth) {
-                // common case, no branch per entry: every slot stores at the current top and the top only
-                // moves for the slots that were hit (the stores beyond it are overwritten or never read)
+        npend = 0;
+    };
+
+    for (;;) {
+        uint32_t ref[8];
+        uint32_t leaf_mask = 0, inner_mask = 0;  // bit k = ray-order position
+        if (walking) {
+            RT_PROF_POINT(0);  // block visits
+            const uint32_t first = cur >> 8, present = cur & 0xffu;
+            const float entry_best = best;
+            // All child records are fetched before any is tested, with no branch around the loads (an
+            // absent child re-reads the block's first record): one memory latency per block instead of
+            // one per present child.
+            float4 ra[8], rb[8];
 #pragma unroll
-                for (int k = 7; k >= 1; --k) {
-                    st.lds[sp * st.lds_stride] = ref[k];
-                    sp += (int)((rest >> k) & 1u);
-                }
-            } else {
-#pragma unroll
-                for (int k = 7; k >= 1; --k)
-                    if ((rest >> k) & 1u) st.put(sp++, ref[k]);
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t oct = (uint32_t)k ^ sign;
+                const uint32_t below = (uint32_t)__popc(present & ((1u << oct) - 1u));
+                const size_t idx = (size_t)first + (((present >> oct) & 1u) ? below : 0u);
+                ra[k] = S.recs[2 * idx];
+                rb[k] = S.recs[2 * idx + 1];
             }
 #pragma unroll
-            for (int k = 7; k >= 0; --k) cur = ((inner_mask >> k) & 1u) ? ref[k] : cur;
-            continue;
+            for (int k = 0; k < 8; ++k) {  // no branch per slot: an absent slot's result is masked out
+                const uint32_t oct = (uint32_t)k ^ sign;
+                const float4 a = ra[k], b = rb[k];
+                float tn = 0.0f, tf = entry_best;
+                {
+                    const float lo = fmaf(a.x, inv.x, -oi.x), hi = fmaf(a.w, inv.x, -oi.x);
+                    tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+                }
+                {
+                    const float lo = fmaf(a.y, inv.y, -oi.y), hi = fmaf(b.x, inv.y, -oi.y);
+                    tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+                }
+                {
+                    const float lo = fmaf(a.z, inv.z, -oi.z), hi = fmaf(b.y, inv.z, -oi.z);
+                    tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+                }
+                const uint32_t hit = (((present >> oct) & 1u) != 0u && tn <= tf) ? (1u << k) : 0u;
+                ref[k] = __float_as_uint(b.z);
+                const bool is_leaf = (__float_as_uint(b.w) & kLeaf) != 0u;
+                leaf_mask |= is_leaf ? hit : 0u;
+                inner_mask |= is_leaf ? 0u : hit;
+            }
         }
-        if (sp == 0) break;
-        cur = st.get(--sp);
+        // room for this visit's leaves in every lane's queue?
+        if (__ballot(npend + (uint32_t)__popc(leaf_mask) > (uint32_t)kPendCap) != 0ull) {
+            flush();
+            if (ANY && occluded) break;
+        }
+        if (leaf_mask) {
+            // branch-free append in ray order: every slot stores at the queue's end, which only moves for hit leaves
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                pend[npend * st.lds_stride] = ref[k];
+                npend += (leaf_mask >> k) & 1u;
+            }
+        }
+        if (walking) {
+            if (inner_mask) {
+                // far-to-near pushes of everything but the nearest, which is entered directly
+                const uint32_t rest = inner_mask & (inner_mask - 1u);
+                if (sp + 7 <= kLdsStackDepth) {
+                    // common case, no branch per entry: every slot stores at the current top and the top only
+                    // moves for the slots that were hit (the stores beyond it are overwritten or never read)
+#pragma unroll
+                    for (int k = 7; k >= 1; --k) {
+                        st.lds[sp * st.lds_stride] = ref[k];
+                        sp += (int)((rest >> k) & 1u);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 7; k >= 1; --k)
+                        if ((rest >> k) & 1u) st.put(sp++, ref[k]);
+                }
+#pragma unroll
+                for (int k = 7; k >= 0; --k) cur = ((inner_mask >> k) & 1u) ? ref[k] : cur;
+            } else if (sp == 0) {
+                walking = false;
+            } else {
+                cur = st.get(--sp);
+            }
+        }
+        const int n_walking = __popcll(__ballot(walking));
+        const int n_holding = __popcll(__ballot(npend > 0u));
+        if (n_holding > 0 && n_holding >= (n_walking < kFlushLanes ? n_walking : kFlushLanes)) {
+            flush();
+            if (ANY && occluded) break;
+        }
+        if (!walking && npend == 0u) break;
     }
     *t_out = best;
     *prim_out = best_prim;

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(Batch B, DCamera cam, Work Wk
 }
 
 __global__ __launch_bounds__(kBlock) void k_extend(DScene S, Work Wk, const uint32_t* queue, uint32_t n) {
-    __shared__ uint32_t s_stack[kLdsStackDepth * kBlock];
+    __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlock;
     const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride};
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, uint3
 template <bool PACKET>
 __global__ __launch_bounds__(kBlock, 4) void k_shadow(DScene S, Batch B, Work Wk, uint32_t n_hits, int bounce,
                                                    int group, int group_shift, const uint32_t* pair_counter) {
-    __shared__ uint32_t s_stack[PACKET ? (kBlock / 64) * kPacketStackDepth : kLdsStackDepth * kBlock];
+    __shared__ uint32_t s_stack[PACKET ? (kBlock / 64) * kPacketStackDepth : kLdsPerLane * kBlock];
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlock;
     const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride};
@@ -348,6 +348,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_shadow(DScene S, Batch B, Work Wk
                     dir = scale3(1.0f / dist, ld);
                 }
             }
+            RT_PROF_POINT(2);  // shadow-ray rounds
             if (PACKET) {
                 vis = traced && !packet_occluded(S, wave_stack, traced, p, dir, 0.01f, dist);
             } else if (traced) {
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float* accum, int n_pi
 
 __global__ __launch_bounds__(kBlock) void k_trace_probe(DScene S, Work Wk, const float* rays, uint32_t n, int any_hit,
                                                         int* prim_out, float* t_out) {
-    __shared__ uint32_t s_stack[kLdsStackDepth * kBlock];
+    __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlock;
     const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride};
@@ -990,5 +991,17 @@ int rt_camera_rays(rt_scene* s, const rt_image_spec* spec, uint64_t seed, const 
     if (e != hipSuccess) return fail(RT_ERR_DEVICE, hipGetErrorString(e));
     return RT_OK;
 }
+
+#ifdef RTGO_PROF
+int rt_debug_prof(unsigned long long* out8, int reset) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(rtgo::g_prof), 8 * sizeof(unsigned long long)));
+    if (reset) {
+        const unsigned long long z[8] = {};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtgo::g_prof), z, sizeof(z)));
+    }
+    return RT_OK;
+}
+#endif
 
 }  // extern "C"

@@ -1,19 +1,22 @@
+"""Lane-utilisation of the shadow kernel's loops, from the instrumented build (make -C raytracer-go_amd/csrc prof).
+Run on the GPU box: python scripts/prof_loops.py [rows]"""
 import ctypes, importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 backend = importlib.import_module("raytracer-go_amd.backend")
 backend.LIB_PATH = os.path.join(ROOT, "raytracer-go_amd/csrc/librtgo_prof.so")
 scenes = importlib.import_module("raytracer-go_amd.scenes")
-import numpy as np
-spec, scene = scenes.config3(1920, 270, 64, 16, asset_dir=os.path.join(ROOT, "tests/golden"))
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1080
+spec, scene = scenes.config3(1920, rows, 64 if rows < 1080 else 16, 16, asset_dir=os.path.join(ROOT, "tests/golden"))
 dev = backend.DeviceScene(scene)
-acc, st = dev.render_accum(spec)
 out = (ctypes.c_ulonglong * 8)()
-backend.lib().rt_debug_prof(out)
+L = backend.lib()
+acc, st = dev.render_accum(spec)
+L.rt_debug_prof(out, 0)
 v = list(out)
-waves = st.rays_shadow / 64
-print("shadow rays", st.rays_shadow, "ms_shadow", st.ms_shadow)
-print("node iters: wave-level %.1f per wave-ray, lane-level %.1f per ray, util %.2f" % (v[0] / waves, v[1] / st.rays_shadow, v[1] / (64 * v[0])))
-print("leaf iters: wave-level %.1f per wave-ray, lane-level %.1f per ray, util %.2f" % (v[2] / waves, v[3] / st.rays_shadow, v[3] / (64 * v[2])))
-print("prim tests: wave-level %.1f per wave-ray, lane-level %.1f per ray, util %.2f" % (v[4] / waves, v[5] / st.rays_shadow, v[5] / (64 * v[4])))
-print("uniform node iters: %.1f per wave-ray (%.2f of node iters)" % (v[6] / waves, v[6] / v[0]))
+# points 0/1 also count the primary rays' traversal (k_extend): 3 % of the rays at config 3
+rounds = v[4]
+print("shadow rays", st.rays_shadow, "ms_shadow %.1f" % st.ms_shadow, "wave rounds", rounds, "lanes/round %.1f" % (v[5] / max(1, rounds)))
+for name, i in (("block visits", 0), ("shape tests", 1)):
+    print("%-12s: %.1f per wave round, %.1f per ray, lane utilisation %.2f" %
+          (name, v[2 * i] / rounds, v[2 * i + 1] / st.rays_shadow, v[2 * i + 1] / (64.0 * v[2 * i])))
