@@ -189,17 +189,20 @@ __device__ unsigned long long g_prof[8];  // [2i] = times a wavefront passed poi
 // instead of a heap.  Per block: (1) every present child's box is slab-tested against the best t
 // known at block entry, in ray order k = 0..7, slot = k ^ sign mask; (2) hit leaf children are queued
 // in that order; (3) hit inner children are pushed far-to-near and the nearest is entered.
-// The queued leaves' shapes are intersected in queue order, a hit accepted iff t > 0 && t < best
-// (strict: first found wins ties, as :101) — but not right away: a wavefront runs its shape loop only
-// once enough of its lanes hold queued leaves (kFlushLanes, or as many as are still walking), because
-// a shape loop entered for the few lanes that hit a leaf in the current block ran at 16 % lane
-// utilisation and was half of the kernel's instructions.  Holding a leaf back cannot change the
-// result: the shapes are still tested in the same order, and a box that a smaller `best` would have
-// culled holds no hit below that `best`.
-// ANY = shadow-ray form of doesReachLight (light.go:141-160): first accepted t <= tmax ends it.
+// The queued leaves' shapes are intersected later, when enough lanes of the wavefront hold leaves
+// (kFlushLanes, or as many lanes as are still walking): a shape loop entered for the few lanes that hit
+// a leaf in the current block ran at 16 % lane utilisation and was half the kernel's instructions.
+// Holding a leaf back cannot change the result: a lane's shapes are still tested in the same order,
+// and a box that a smaller `best` would have culled holds no hit below that `best`.
 constexpr int kLdsStackDepth = 24;
-constexpr int kPendCap = 8;     // leaves a lane can hold back (one block visit adds at most 8)
-constexpr int kFlushLanes = 32; // run the shape loop when this many lanes hold leaves
+#ifndef RTGO_PEND_CAP
+#define RTGO_PEND_CAP 12
+#endif
+#ifndef RTGO_FLUSH_LANES
+#define RTGO_FLUSH_LANES 48
+#endif
+constexpr int kPendCap = RTGO_PEND_CAP;        // leaves a lane can hold back (one block visit adds at most 8)
+constexpr int kFlushLanes = RTGO_FLUSH_LANES;  // run the shape loop when this many lanes hold leaves
 constexpr int kLdsPerLane = kLdsStackDepth + kPendCap + 1;  // +1: the branch-free append stores one past the last
 struct TraceStack {
     uint32_t* lds;        // &s_stack[threadIdx.x], entries kBlock apart: [0, kLdsStackDepth) stack, then the leaf queue
@@ -212,21 +215,120 @@ struct TraceStack {
         return sp < kLdsStackDepth ? lds[sp * lds_stride] : overflow[(size_t)(sp - kLdsStackDepth) * stride];
     }
 };
+struct TraceRay {
+    f3 o, d, inv, oi;
+    uint32_t sign;
+};
+RT_DEV TraceRay make_trace_ray(f3 o, f3 d) {
+    TraceRay r;
+    r.o = o; r.d = d;
+    r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    r.oi = mk3(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
+    r.sign = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    return r;
+}
 
-template <bool ANY>
-RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tmin, float tmax, float* t_out, int* prim_out) {
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const f3 oi = mk3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
-    const uint32_t sign = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-    float best = ANY ? tmax : 3.402823466e+38f;
+// (1): slab tests of the 8 slots of block `cur` in ray order; bit k of the masks = ray-order position k
+RT_DEV void visit_block(const DScene& S, uint32_t cur, const TraceRay& r, float entry_best, uint32_t ref[8],
+                        uint32_t* leaf_mask, uint32_t* inner_mask) {
+    RT_PROF_POINT(0);  // block visits
+    const uint32_t first = cur >> 8, present = cur & 0xffu;
+    // All child records are fetched before any is tested, with no branch around the loads (an absent
+    // child re-reads the block's first record): one memory latency per block instead of one per child.
+    float4 ra[8], rb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t oct = (uint32_t)k ^ r.sign;
+        const uint32_t below = (uint32_t)__popc(present & ((1u << oct) - 1u));
+        const size_t idx = (size_t)first + (((present >> oct) & 1u) ? below : 0u);
+        ra[k] = S.recs[2 * idx];
+        rb[k] = S.recs[2 * idx + 1];
+    }
+    uint32_t lm = 0, im = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {  // no branch per slot: an absent slot's result is masked out
+        const uint32_t oct = (uint32_t)k ^ r.sign;
+        const float4 a = ra[k], b = rb[k];
+        float tn = 0.0f, tf = entry_best;
+        {
+            const float lo = fmaf(a.x, r.inv.x, -r.oi.x), hi = fmaf(a.w, r.inv.x, -r.oi.x);
+            tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+        }
+        {
+            const float lo = fmaf(a.y, r.inv.y, -r.oi.y), hi = fmaf(b.x, r.inv.y, -r.oi.y);
+            tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+        }
+        {
+            const float lo = fmaf(a.z, r.inv.z, -r.oi.z), hi = fmaf(b.y, r.inv.z, -r.oi.z);
+            tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+        }
+        const uint32_t hit = (((present >> oct) & 1u) != 0u && tn <= tf) ? (1u << k) : 0u;
+        ref[k] = __float_as_uint(b.z);
+        const bool is_leaf = (__float_as_uint(b.w) & kLeaf) != 0u;
+        lm |= is_leaf ? hit : 0u;
+        im |= is_leaf ? 0u : hit;
+    }
+    *leaf_mask = lm;
+    *inner_mask = im;
+}
+// (2): branch-free append in ray order — every slot stores at the queue's end, which only moves for hit leaves
+RT_DEV void queue_leaves(uint32_t* pend, uint32_t stride, const uint32_t ref[8], uint32_t leaf_mask, uint32_t* npend) {
+    if (leaf_mask) {
+        uint32_t n = *npend;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            pend[n * stride] = ref[k];
+            n += (leaf_mask >> k) & 1u;
+        }
+        *npend = n;
+    }
+}
+// (3): far-to-near pushes of every hit inner child but the nearest, which becomes `cur`; with no hit
+// inner child the next block comes off the stack.  Returns false when there is no next block.
+RT_DEV bool next_block(const TraceStack& st, const uint32_t ref[8], uint32_t inner_mask, uint32_t* cur, int* sp_io) {
+    int sp = *sp_io;
+    if (inner_mask) {
+        const uint32_t rest = inner_mask & (inner_mask - 1u);
+        if (sp + 7 <= kLdsStackDepth) {
+            // common case, no branch per entry: every slot stores at the current top and the top only
+            // moves for the slots that were hit (the stores beyond it are overwritten or never read)
+#pragma unroll
+            for (int k = 7; k >= 1; --k) {
+                st.lds[sp * st.lds_stride] = ref[k];
+                sp += (int)((rest >> k) & 1u);
+            }
+        } else {
+#pragma unroll
+            for (int k = 7; k >= 1; --k)
+                if ((rest >> k) & 1u) st.put(sp++, ref[k]);
+        }
+        // (static loads first: a select between array elements must not become an indexed load from memory)
+        const uint32_t r0 = ref[0], r1 = ref[1], r2 = ref[2], r3 = ref[3], r4 = ref[4], r5 = ref[5], r6 = ref[6], r7 = ref[7];
+        uint32_t c = r7;
+        c = (inner_mask & 64u) ? r6 : c; c = (inner_mask & 32u) ? r5 : c; c = (inner_mask & 16u) ? r4 : c;
+        c = (inner_mask & 8u) ? r3 : c;  c = (inner_mask & 4u) ? r2 : c;  c = (inner_mask & 2u) ? r1 : c;
+        c = (inner_mask & 1u) ? r0 : c;
+        *cur = c;
+        *sp_io = sp;
+        return true;
+    }
+    if (sp == 0) return false;
+    *cur = st.get(--sp);
+    *sp_io = sp;
+    return true;
+}
+
+// Nearest hit (camera and scattered rays).  Accepts t > 0 && t < best (strict: first found wins ties,
+// accelerationstructures.go:101).
+RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tmin, float* t_out, int* prim_out) {
+    const TraceRay r = make_trace_ray(o, d);
+    float best = 3.402823466e+38f;
     int best_prim = -1;
     uint32_t cur = S.root_ref;
     int sp = 0;
     bool walking = true;   // has a block to visit
-    bool occluded = false; // ANY: an accepted hit was found
     uint32_t npend = 0;    // queued leaves
     uint32_t* const pend = st.lds + kLdsStackDepth * st.lds_stride;
-
     // the shape loop: one flat loop over the shapes of all queued leaves, in queue order
     auto flush = [&]() {
         uint32_t qhead = 0, pnext = 0, pleft = 0;
@@ -241,101 +343,22 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
             RT_PROF_POINT(1);  // shape tests
             const uint32_t prim = pnext++;
             --pleft;
-            const float t = prim_hit<ANY>(S, prim, o, d, tmin, best);
-            if (ANY) {
-                if (t > 0.0f && t <= best) { best = t; best_prim = (int)prim; occluded = true; break; }
-            } else if (t > 0.0f && t < best) { best = t; best_prim = (int)prim; }
+            const float t = prim_hit<false>(S, prim, o, d, tmin, best);
+            if (t > 0.0f && t < best) { best = t; best_prim = (int)prim; }
         }
         npend = 0;
     };
-
     for (;;) {
         uint32_t ref[8];
-        uint32_t leaf_mask = 0, inner_mask = 0;  // bit k = ray-order position
-        if (walking) {
-            RT_PROF_POINT(0);  // block visits
-            const uint32_t first = cur >> 8, present = cur & 0xffu;
-            const float entry_best = best;
-            // All child records are fetched before any is tested, with no branch around the loads (an
-            // absent child re-reads the block's first record): one memory latency per block instead of
-            // one per present child.
-            float4 ra[8], rb[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t oct = (uint32_t)k ^ sign;
-                const uint32_t below = (uint32_t)__popc(present & ((1u << oct) - 1u));
-                const size_t idx = (size_t)first + (((present >> oct) & 1u) ? below : 0u);
-                ra[k] = S.recs[2 * idx];
-                rb[k] = S.recs[2 * idx + 1];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {  // no branch per slot: an absent slot's result is masked out
-                const uint32_t oct = (uint32_t)k ^ sign;
-                const float4 a = ra[k], b = rb[k];
-                float tn = 0.0f, tf = entry_best;
-                {
-                    const float lo = fmaf(a.x, inv.x, -oi.x), hi = fmaf(a.w, inv.x, -oi.x);
-                    tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
-                }
-                {
-                    const float lo = fmaf(a.y, inv.y, -oi.y), hi = fmaf(b.x, inv.y, -oi.y);
-                    tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
-                }
-                {
-                    const float lo = fmaf(a.z, inv.z, -oi.z), hi = fmaf(b.y, inv.z, -oi.z);
-                    tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
-                }
-                const uint32_t hit = (((present >> oct) & 1u) != 0u && tn <= tf) ? (1u << k) : 0u;
-                ref[k] = __float_as_uint(b.z);
-                const bool is_leaf = (__float_as_uint(b.w) & kLeaf) != 0u;
-                leaf_mask |= is_leaf ? hit : 0u;
-                inner_mask |= is_leaf ? 0u : hit;
-            }
-        }
+        uint32_t leaf_mask = 0, inner_mask = 0;
+        if (walking) visit_block(S, cur, r, best, ref, &leaf_mask, &inner_mask);
         // room for this visit's leaves in every lane's queue?
-        if (__ballot(npend + (uint32_t)__popc(leaf_mask) > (uint32_t)kPendCap) != 0ull) {
-            flush();
-            if (ANY && occluded) break;
-        }
-        if (leaf_mask) {
-            // branch-free append in ray order: every slot stores at the queue's end, which only moves for hit leaves
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                pend[npend * st.lds_stride] = ref[k];
-                npend += (leaf_mask >> k) & 1u;
-            }
-        }
-        if (walking) {
-            if (inner_mask) {
-                // far-to-near pushes of everything but the nearest, which is entered directly
-                const uint32_t rest = inner_mask & (inner_mask - 1u);
-                if (sp + 7 <= kLdsStackDepth) {
-                    // common case, no branch per entry: every slot stores at the current top and the top only
-                    // moves for the slots that were hit (the stores beyond it are overwritten or never read)
-#pragma unroll
-                    for (int k = 7; k >= 1; --k) {
-                        st.lds[sp * st.lds_stride] = ref[k];
-                        sp += (int)((rest >> k) & 1u);
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 7; k >= 1; --k)
-                        if ((rest >> k) & 1u) st.put(sp++, ref[k]);
-                }
-#pragma unroll
-                for (int k = 7; k >= 0; --k) cur = ((inner_mask >> k) & 1u) ? ref[k] : cur;
-            } else if (sp == 0) {
-                walking = false;
-            } else {
-                cur = st.get(--sp);
-            }
-        }
+        if (__ballot(npend + (uint32_t)__popc(leaf_mask) > (uint32_t)kPendCap) != 0ull) flush();
+        queue_leaves(pend, st.lds_stride, ref, leaf_mask, &npend);
+        if (walking) walking = next_block(st, ref, inner_mask, &cur, &sp);
         const int n_walking = __popcll(__ballot(walking));
         const int n_holding = __popcll(__ballot(npend > 0u));
-        if (n_holding > 0 && n_holding >= (n_walking < kFlushLanes ? n_walking : kFlushLanes)) {
-            flush();
-            if (ANY && occluded) break;
-        }
+        if (n_holding > 0 && n_holding >= (n_walking < kFlushLanes ? n_walking : kFlushLanes)) flush();
         if (!walking && npend == 0u) break;
     }
     *t_out = best;
@@ -343,87 +366,56 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
     return best_prim >= 0;
 }
 
-// ---- wavefront-packet any-hit traversal (shadow rays) ----------------------------------------
-// The 64 shadow rays of a wavefront go to the same light from neighbouring hit points, so they
-// walk nearly the same nodes.  The traversal is therefore WAVE-UNIFORM: one stack per wavefront
-// (LDS), a node is entered when any live lane hits its box, and node / shape data are fetched with
-// SCALAR loads (constant address space -> s_load through the scalar cache) instead of 64 per-lane
-// copies through the vector L1 — the per-lane form is bound by vector-memory return bandwidth.
-// Per lane the outcome is the same as traverse<true>: a lane tests a shape iff it hits that leaf's
-// box (child boxes are nested in their parents' and the slab test is monotone, so it then hits
-// every ancestor too), and "occluded" is an OR over those tests, which has no order.
-#define RT_CONST __attribute__((address_space(4)))
-typedef float v8f __attribute__((ext_vector_type(8)));  // one child record: {min.xyz, max.xyz, w0, w1}
-typedef float v4f __attribute__((ext_vector_type(4)));
-template <class T> RT_DEV const RT_CONST T* as_constant(const void* p) {
-    return (const RT_CONST T*)(uintptr_t)p;
-}
-constexpr int kPacketStackDepth = 128;  // entries per wavefront in LDS
-
-// alive: this lane has a ray.  Returns true if this lane's ray is occluded.
-RT_DEV bool packet_occluded(const DScene& S, uint32_t* wave_stack, bool alive, f3 o, f3 d, float tmin, float tmax) {
-    const RT_CONST v8f* recs = as_constant<v8f>(S.recs);
-    const RT_CONST v4f* prims = as_constant<v4f>(S.prims);
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const f3 oi = mk3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
-    unsigned long long live = __ballot(alive);
-    if (live == 0ull) return false;
-    // ray order of the first live lane: any order is valid for any-hit, near-first exits sooner
-    const uint32_t my_sign = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-    const uint32_t sign = (uint32_t)__builtin_amdgcn_readlane((int)my_sign, __ffsll((long long)live) - 1);
-    bool occluded = false;
+// Shadow rays: "is anything hit with tmin <= t <= tmax" (doesReachLight, light.go:141-160); the first
+// accepted hit ends the ray.  Same walk and leaf queue as traverse().
+// (Dealing the queued leaves out evenly over all 64 lanes — prefix sum, owner search, cross-lane ray
+// fetch — was measured: shape-loop utilisation 0.20 -> 0.43, frame 1.31 s -> 1.65 s; the bookkeeping per
+// flush and the extra live registers cost more than the idle lanes.  Branch exp/balanced-shape-loop.)
+RT_DEV bool occluded(const DScene& S, const TraceStack& st, f3 o, f3 d, float tmin, float tmax) {
+    const TraceRay r = make_trace_ray(o, d);
     uint32_t cur = S.root_ref;
     int sp = 0;
-    for (;;) {
-        const uint32_t first = cur >> 8, present = cur & 0xffu;
-        for (int k = 7; k >= 0; --k) {  // far to near: the nearest inner child ends on top of the stack
-            const uint32_t oct = (uint32_t)k ^ sign;
-            if (!((present >> oct) & 1u)) continue;
-            const uint32_t idx = first + (uint32_t)__builtin_popcount(present & ((1u << oct) - 1u));
-            const v8f r = recs[idx];
-            const uint32_t w0 = __float_as_uint(r[6]), w1 = __float_as_uint(r[7]);
-            float tn = 0.0f, tf = tmax;
-            {
-                const float lo = fmaf(r[0], inv.x, -oi.x), hi = fmaf(r[3], inv.x, -oi.x);
-                tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+    bool walking = true;
+    bool occ = false;
+    uint32_t npend = 0;
+    uint32_t* const pend = st.lds + kLdsStackDepth * st.lds_stride;
+    auto flush = [&]() {
+        uint32_t qhead = 0, pnext = 0, pleft = 0;
+        for (;;) {
+            if (pleft == 0) {
+                if (qhead == npend) break;
+                const uint32_t leaf = pend[qhead * st.lds_stride];
+                ++qhead;
+                pnext = leaf >> 8;
+                pleft = leaf & 0xffu;
             }
-            {
-                const float lo = fmaf(r[1], inv.y, -oi.y), hi = fmaf(r[4], inv.y, -oi.y);
-                tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
-            }
-            {
-                const float lo = fmaf(r[2], inv.z, -oi.z), hi = fmaf(r[5], inv.z, -oi.z);
-                tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
-            }
-            const bool hit = alive && !occluded && tn <= tf;
-            if (__ballot(hit) == 0ull) continue;
-            if (w1 & kLeaf) {
-              const uint32_t pfirst = w0 >> 8, pcount = w0 & 0xffu;
-              for (uint32_t c = 0; c < pcount; ++c) {
-                const size_t pi = (size_t)(pfirst + c);
-                const v4f p0 = prims[3 * pi], p1 = prims[3 * pi + 1], p2 = prims[3 * pi + 2];
-                const uint32_t bits = __float_as_uint(p2[1]);
-                if (hit && !occluded) {
-                    float t;
-                    if (bits & kPrimTriangle)
-                        t = triangle_occludes(mk3(p0[0], p0[1], p0[2]), mk3(p0[3], p1[0], p1[1]), mk3(p1[2], p1[3], p2[0]),
-                                         (bits & kPrimSingleSided) != 0, o, d, tmin, tmax);
-                    else
-                        t = sphere_hit(make_float4(p0[0], p0[1], p0[2], p0[3]), o, d, tmin, tmax);
-                    if (t > 0.0f && t <= tmax) occluded = true;
-                }
-              }
-            } else {
-                if (sp < kPacketStackDepth) wave_stack[sp] = w0;  // bound checked on the host
-                ++sp;
-            }
+            RT_PROF_POINT(1);  // shape tests
+            const uint32_t prim = pnext++;
+            --pleft;
+            const float t = prim_hit<true>(S, prim, o, d, tmin, tmax);
+            if (t > 0.0f && t <= tmax) { occ = true; break; }
         }
-        live = __ballot(alive && !occluded);
-        if (live == 0ull || sp == 0) break;
-        --sp;
-        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_stack[sp]);
+        npend = 0;
+    };
+    for (;;) {
+        uint32_t ref[8];
+        uint32_t leaf_mask = 0, inner_mask = 0;
+        if (walking) visit_block(S, cur, r, tmax, ref, &leaf_mask, &inner_mask);
+        if (__ballot(npend + (uint32_t)__popc(leaf_mask) > (uint32_t)kPendCap) != 0ull) {
+            flush();
+            if (occ) break;
+        }
+        queue_leaves(pend, st.lds_stride, ref, leaf_mask, &npend);
+        if (walking) walking = next_block(st, ref, inner_mask, &cur, &sp);
+        const int n_walking = __popcll(__ballot(walking));
+        const int n_holding = __popcll(__ballot(npend > 0u));
+        if (n_holding > 0 && n_holding >= (n_walking < kFlushLanes ? n_walking : kFlushLanes)) {
+            flush();
+            if (occ) break;
+        }
+        if (!walking && npend == 0u) break;
     }
-    return occluded;
+    return occ;
 }
 
 // ---- textures (texture.go:27-53) and UV maps (shape.go:100-105, 213-227) --------------------

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(DScene S, Work Wk, const uint
         const uint32_t slot = queue[i];
         const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
         float t; int prim;
-        traverse<false>(S, st, mk3(ro.x, ro.y, ro.z), mk3(rdv.x, rdv.y, rdv.z), 0.0f, 0.0f, &t, &prim);
+        traverse(S, st, mk3(ro.x, ro.y, ro.z), mk3(rdv.x, rdv.y, rdv.z), 0.0f, &t, &prim);
         Wk.ray_o[slot].w = t;
         Wk.ray_d[slot].w = __int_as_float(prim);
     }
@@ -288,16 +288,12 @@ __global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, uint3
 // One lane per (PhongBlinn hit, positional light, repetition lane).  group = lanes per (hit, light):
 // a power of two <= 64; each lane runs repetitions r, r+group, ...  The visible repetitions of a
 // (hit, light) are counted with a ballot popcount: integer, so the result has no summation order.
-// PACKET: wave-uniform traversal with scalar node loads (device_math.hpp packet_occluded); the
-// per-lane form remains for trees whose stack bound exceeds the wavefront stack in LDS.
-template <bool PACKET>
 __global__ __launch_bounds__(kBlock, 4) void k_shadow(DScene S, Batch B, Work Wk, uint32_t n_hits, int bounce,
                                                    int group, int group_shift, const uint32_t* pair_counter) {
-    __shared__ uint32_t s_stack[PACKET ? (kBlock / 64) * kPacketStackDepth : kLdsPerLane * kBlock];
+    __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlock;
     const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride};
-    uint32_t* wave_stack = s_stack + (threadIdx.x >> 6) * kPacketStackDepth;
     const unsigned long long total = (unsigned long long)(*pair_counter) * group;  // written by k_phong_pairs, same stream
     const unsigned long long rounds = (total + gstride - 1) / gstride;
     const int lane = (int)__lane_id();
@@ -349,12 +345,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_shadow(DScene S, Batch B, Work Wk
                 }
             }
             RT_PROF_POINT(2);  // shadow-ray rounds
-            if (PACKET) {
-                vis = traced && !packet_occluded(S, wave_stack, traced, p, dir, 0.01f, dist);
-            } else if (traced) {
-                float t; int prim;
-                vis = !traverse<true>(S, st, p, dir, 0.01f, dist, &t, &prim);
-            }
+            if (traced) vis = !occluded(S, st, p, dir, 0.01f, dist);
             const unsigned long long m = __ballot(vis);
             count += (uint32_t)__popcll(m & gmask);
         }
@@ -426,15 +417,15 @@ __global__ __launch_bounds__(kBlock) void k_trace_probe(DScene S, Work Wk, const
     const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride};
     for (uint32_t i = gtid; i < n; i += gstride) {
         const float* q = rays + (size_t)i * 8;
-        float t; int prim;
         if (any_hit) {
-            const bool occ = traverse<true>(S, st, mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), q[6], q[7], &t, &prim);
-            prim_out[i] = occ ? 1 : 0;
+            prim_out[i] = occluded(S, st, mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), q[6], q[7]) ? 1 : 0;
+            t_out[i] = 0.0f;
         } else {
-            traverse<false>(S, st, mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), q[6], 0.0f, &t, &prim);
+            float t; int prim;
+            traverse(S, st, mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), q[6], &t, &prim);
             prim_out[i] = prim >= 0 ? S.prim_ids[prim] : -1;  // report the position in Scene.Shapes
+            t_out[i] = t;
         }
-        t_out[i] = t;
     }
 }
 
@@ -849,14 +840,8 @@ int rt_render_accum_device(rt_scene* s, const rt_image_spec* spec, const rt_part
                                                s->d, wk, np, pair_counter);
                             if (timed) HIP_TRY(hipEventRecord(ev[3], stream));  // ms_shadow brackets k_shadow alone
                             if (reps > 0) {
-                                // The per-lane form measured faster on config 3 (2.71 s vs 3.08 s per frame): the packet form
-                                // serialises the union of the nodes its 64 rays touch and becomes scalar-ALU bound.
-                                static const bool use_packet = std::getenv("RTGO_SHADOW_PACKET") != nullptr;  // A/B switch
                                 const int grid = grid_for(n_pairs * group);  // upper bound; the kernel reads the real pair count
-                                if (s->info.stack_bound <= kPacketStackDepth && use_packet)
-                                    hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kBlock), 0, stream, s->d, B, wk, np, b, group, group_shift, pair_counter);
-                                else
-                                    hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kBlock), 0, stream, s->d, B, wk, np, b, group, group_shift, pair_counter);
+                                hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(kBlock), 0, stream, s->d, B, wk, np, b, group, group_shift, pair_counter);
                             }
                         }
                         if (timed) HIP_TRY(hipEventRecord(ev[4], stream));
