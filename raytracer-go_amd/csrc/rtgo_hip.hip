@@ -80,7 +80,9 @@ struct Work {
     uint32_t* queue[2];
     uint32_t* phong_queue;
     uint32_t* vis;   // visible-repetition count per (phong hit, positional light)
-    uint32_t* pairs; // (hit, light) pairs whose shading term is not exactly zero: light * n_hits + hit
+    uint32_t* pairs; // (hit, light) pairs whose shading term is not exactly zero: light * n_hits + hit, light-major
+    uint32_t* pair_seg;    // the same before compaction: light l's hits at [l * n_hits, l * n_hits + light_count[l])
+    uint32_t* light_count; // [0, L) pairs per positional light, [L, 2L) their exclusive prefix sums
     uint32_t* counters;  // [0..D] ray-queue sizes per bounce, [D+1..2D] phong-queue sizes, [2D+2..3] shadow rays (u64),
                          // [2D+4..3D+3] pair-queue sizes per bounce
     uint32_t* overflow;  // traversal stack spill
@@ -262,27 +264,46 @@ RT_DEV PhongHit load_phong_hit(const DScene& S, const Work& Wk, uint32_t slot) {
     return h;
 }
 
-// One lane per (positional light, PhongBlinn hit), light-major.  A pair whose shading term is exactly
-// (0,0,0) — light behind the surface and no specular lobe towards it — adds count/reps * 0 whatever its
-// soft-shadow rays would find, so those rays are never generated: only the other pairs are queued for
-// k_shadow.  Every pair's visible-repetition count starts at 0 here.
-__global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, uint32_t n_hits, uint32_t* pair_counter) {
-    const unsigned long long idx = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
-    const unsigned long long total = (unsigned long long)n_hits * S.n_pos_lights;
-    bool keep = false;
-    if (idx < total) {
-        const uint32_t lp = (uint32_t)(idx / n_hits);
-        const uint32_t hit_i = (uint32_t)(idx - (unsigned long long)lp * n_hits);
-        const PhongHit h = load_phong_hit(S, Wk, Wk.phong_queue[hit_i]);
-        int q = 0;  // positional light #lp
-        for (int seen = -1; q < S.n_lights; ++q)
-            if (S.lights[q].kind != RT_LIGHT_AMBIENT && ++seen == (int)lp) break;
-        const f3 comb = phong_term(S.lights[q], h.m, h.mc, h.p, h.nrm, h.d);
-        keep = !(comb.x == 0.0f && comb.y == 0.0f && comb.z == 0.0f);
-        Wk.vis[(size_t)hit_i * S.n_pos_lights + lp] = 0u;
+// One lane per PhongBlinn hit.  A (hit, light) pair whose shading term is exactly (0,0,0) — light behind
+// the surface and no specular lobe towards it — adds count/reps * 0 whatever its soft-shadow rays would
+// find, so those rays are never generated: only the other pairs are queued for k_shadow, per light
+// (segment l of pair_seg), so that the queue k_pair_compact builds from the segments is light-major.
+// Every pair's visible-repetition count starts at 0 here.
+__global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, uint32_t n_hits) {
+    const uint32_t hit_i = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = hit_i < n_hits;
+    PhongHit h{};
+    if (live) h = load_phong_hit(S, Wk, Wk.phong_queue[hit_i]);
+    uint32_t lp = 0;
+    for (int q = 0; q < S.n_lights; ++q) {  // uniform trip count: wave_push is a wavefront operation
+        if (S.lights[q].kind == RT_LIGHT_AMBIENT) continue;
+        bool keep = false;
+        if (live) {
+            const f3 comb = phong_term(S.lights[q], h.m, h.mc, h.p, h.nrm, h.d);
+            keep = !(comb.x == 0.0f && comb.y == 0.0f && comb.z == 0.0f);
+            Wk.vis[(size_t)hit_i * S.n_pos_lights + lp] = 0u;
+        }
+        const uint32_t at = wave_push(&Wk.light_count[lp], keep);
+        if (keep) Wk.pair_seg[(size_t)lp * n_hits + at] = hit_i;
+        ++lp;
     }
-    const uint32_t at = wave_push(pair_counter, keep);
-    if (keep) Wk.pairs[at] = (uint32_t)idx;
+}
+// exclusive prefix sums of the per-light pair counts; the total is the pair-queue length k_shadow reads
+__global__ void k_pair_offsets(Work Wk, int n_pos_lights, uint32_t* pair_counter) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t run = 0;
+    for (int l = 0; l < n_pos_lights; ++l) {
+        Wk.light_count[n_pos_lights + l] = run;
+        run += Wk.light_count[l];
+    }
+    *pair_counter = run;
+}
+__global__ __launch_bounds__(kBlock) void k_pair_compact(Work Wk, uint32_t n_hits, int n_pos_lights) {
+    const unsigned long long idx = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= (unsigned long long)n_hits * n_pos_lights) return;
+    const uint32_t l = (uint32_t)(idx / n_hits);
+    const uint32_t j = (uint32_t)(idx - (unsigned long long)l * n_hits);
+    if (j < Wk.light_count[l]) Wk.pairs[Wk.light_count[n_pos_lights + l] + j] = l * n_hits + Wk.pair_seg[idx];
 }
 
 // One lane per (PhongBlinn hit, positional light, repetition lane).  group = lanes per (hit, light):
@@ -294,7 +315,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_shadow(DScene S, Batch B, Work Wk
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlock;
     const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride};
-    const unsigned long long total = (unsigned long long)(*pair_counter) * group;  // written by k_phong_pairs, same stream
+    const unsigned long long total = (unsigned long long)(*pair_counter) * group;  // written by k_pair_offsets, same stream
     const unsigned long long rounds = (total + gstride - 1) / gstride;
     const int lane = (int)__lane_id();
     const int gbase = lane & ~(group - 1);
@@ -466,7 +487,7 @@ namespace {
 
 void free_work(rt_scene* s) {
     Work& w = s->wk;
-    void* ptrs[] = {w.ray_o, w.ray_d, w.thr, w.rad, w.queue[0], w.queue[1], w.phong_queue, w.vis, w.pairs, w.counters};
+    void* ptrs[] = {w.ray_o, w.ray_d, w.thr, w.rad, w.queue[0], w.queue[1], w.phong_queue, w.vis, w.pairs, w.pair_seg, w.light_count, w.counters};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     uint32_t* ov = w.overflow; const uint32_t os = w.overflow_stride;
     w = Work{};
@@ -487,6 +508,8 @@ int ensure_work(rt_scene* s, int64_t paths, int depth, int lpos) {
     HIP_TRY(hipMalloc((void**)&w.phong_queue, paths * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w.vis, (size_t)paths * (size_t)(lpos > 0 ? lpos : 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w.pairs, (size_t)paths * (size_t)(lpos > 0 ? lpos : 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&w.pair_seg, (size_t)paths * (size_t)(lpos > 0 ? lpos : 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&w.light_count, (size_t)2 * (size_t)(lpos > 0 ? lpos : 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w.counters, (size_t)(3 * depth + 8) * sizeof(uint32_t)));
     if (s->h_counters) { (void)hipHostFree(s->h_counters); s->h_counters = nullptr; }
     HIP_TRY(hipHostMalloc((void**)&s->h_counters, (size_t)(3 * depth + 8) * sizeof(uint32_t)));
@@ -836,8 +859,11 @@ int rt_render_accum_device(rt_scene* s, const rt_image_spec* spec, const rt_part
                         if (s->d.n_pos_lights > 0) {
                             const unsigned long long n_pairs = (unsigned long long)np * s->d.n_pos_lights;
                             uint32_t* pair_counter = wk.counters + 2 * D + 4 + b;
-                            hipLaunchKernelGGL(k_phong_pairs, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                                               s->d, wk, np, pair_counter);
+                            const int L = s->d.n_pos_lights;
+                            HIP_TRY(hipMemsetAsync(wk.light_count, 0, (size_t)L * sizeof(uint32_t), stream));
+                            hipLaunchKernelGGL(k_phong_pairs, dim3((np + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, wk, np);
+                            hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(64), 0, stream, wk, L, pair_counter);
+                            hipLaunchKernelGGL(k_pair_compact, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, wk, np, L);
                             if (timed) HIP_TRY(hipEventRecord(ev[3], stream));  // ms_shadow brackets k_shadow alone
                             if (reps > 0) {
                                 const int grid = grid_for(n_pairs * group);  // upper bound; the kernel reads the real pair count
