@@ -51,6 +51,7 @@ def lib():
         L.orc_scene_create.argtypes = [C.c_void_p]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_set_leaf_size.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_tree.argtypes = [C.c_void_p, C.c_int]
         L.orc_tree_info.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_trace_rays.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -74,7 +75,9 @@ class OracleScene:
         if not self._h:
             raise RuntimeError(lib().orc_last_error().decode())
         # F32_STACK mirrors the device tree: same shapes-per-leaf rule as the device flattener
-        lib().orc_set_leaf_size(self._h, int(os.environ.get("RTGO_LEAF_SIZE", "4")))
+        octree = os.environ.get("RTGO_TREE") == "octree"
+        lib().orc_set_tree(self._h, 0 if octree else 1)
+        lib().orc_set_leaf_size(self._h, int(os.environ.get("RTGO_LEAF_SIZE", "4" if octree else "6")))
 
     def close(self):
         if self._h:

@@ -181,7 +181,9 @@ struct Scene {
     rt_vec3 cam_from, cam_at, cam_up;
     double aperture, fov;
     std::vector<std::unique_ptr<Node>> pool;
-    Node* root = nullptr;
+    Node* root = nullptr;      // the reference's octree (all fp64 modes; F32_STACK when tree_kind == 0)
+    Node* wide_root = nullptr; // F32_STACK, tree_kind == 1: the device's binned-SAH tree in 8-slot node form
+    int tree_kind = 1;         // device default (RTGO_TREE): 1 = sah, 0 = octree
     int leaf_size = 4;  // F32_STACK: a subtree with at most this many shapes is one leaf (device flattener rule)
     int n_nodes_alloc = 0;
 };
@@ -406,6 +408,172 @@ void build_blocks(Node* root, int leaf_size) {
         build_block(x, leaf_size, collapse);
         for (Node* e : x->slot) if (e && e->count > leaf_size) todo.push_back(e);
     }
+}
+
+// The device's default tree (csrc/octree.cpp build_sah), restated.  Spec:
+//   split(range): boxes and centroid bounds (centroid = centre of the shape's box) of the range; at most
+//     leaf_size shapes -> leaf.  Otherwise, for axis x, y, z with a positive centroid extent: 16 equal
+//     bins over the centroid bounds (bin = int((c - lo) * (16 / extent)), clamped to 15); for every
+//     boundary k = 0..14 with shapes on both sides, cost = area(left boxes) * n_left + area(right boxes)
+//     * n_right; the strictly smallest cost wins (first axis, first boundary on ties).  The range is
+//     split stably (order kept on both sides) by bin <= k; with no valid boundary, in the middle.
+//   widen(node): children = {left, right}; while fewer than 8 and some child is not a leaf, the inner
+//     child with the largest box area (first on ties) is replaced by its left child and its right child
+//     is appended.  Children take slots by the same greedy matching as build_block.  A leaf's shapes
+//     become single-shape children in slots 0.. in range order.
+struct SahShape { V3<double> lo, hi, c; int shape; };
+struct SahSplit { V3<double> lo, hi; int left = -1, right = -1, b = 0, e = 0; };
+inline double box_area(const V3<double>& lo, const V3<double>& hi) {
+    const double dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    return 2.0 * ((dx * dy + dy * dz) + dz * dx);
+}
+inline double axis_of(const V3<double>& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+inline void grow(V3<double>& lo, V3<double>& hi, const V3<double>& l2, const V3<double>& h2) {
+    lo.x = std::fmin(lo.x, l2.x); lo.y = std::fmin(lo.y, l2.y); lo.z = std::fmin(lo.z, l2.z);
+    hi.x = std::fmax(hi.x, h2.x); hi.y = std::fmax(hi.y, h2.y); hi.z = std::fmax(hi.z, h2.z);
+}
+struct SahTree {
+    Scene& sc;
+    int leaf_size;
+    std::vector<SahShape> shp;
+    std::vector<SahSplit> nodes;
+    static constexpr int kBins = 16;
+    static int bin_of(double c, double lo, double scale) {
+        const int k = (int)((c - lo) * scale);
+        return k >= kBins ? kBins - 1 : k;
+    }
+    int split(int b, int e) {
+        const V3<double> big{DBL_MAX, DBL_MAX, DBL_MAX}, small{-DBL_MAX, -DBL_MAX, -DBL_MAX};
+        SahSplit nd;
+        nd.b = b; nd.e = e; nd.lo = big; nd.hi = small;
+        V3<double> clo = big, chi = small;
+        for (int i = b; i < e; ++i) { grow(nd.lo, nd.hi, shp[i].lo, shp[i].hi); grow(clo, chi, shp[i].c, shp[i].c); }
+        const int me = (int)nodes.size();
+        nodes.push_back(nd);
+        if (e - b <= leaf_size) return me;
+        int best_axis = -1, best_k = 0;
+        double best_cost = DBL_MAX;
+        for (int a = 0; a < 3; ++a) {
+            const double ext = axis_of(chi, a) - axis_of(clo, a);
+            if (!(ext > 0)) continue;
+            const double scale = kBins / ext;
+            V3<double> blo[kBins], bhi[kBins];
+            int bn[kBins];
+            for (int k = 0; k < kBins; ++k) { blo[k] = big; bhi[k] = small; bn[k] = 0; }
+            for (int i = b; i < e; ++i) {
+                const int k = bin_of(axis_of(shp[i].c, a), axis_of(clo, a), scale);
+                bn[k]++;
+                grow(blo[k], bhi[k], shp[i].lo, shp[i].hi);
+            }
+            double right_area[kBins]; int right_n[kBins];
+            V3<double> lo = big, hi = small;
+            int cnt = 0;
+            for (int k = kBins - 1; k >= 1; --k) {
+                grow(lo, hi, blo[k], bhi[k]);
+                cnt += bn[k];
+                right_area[k] = cnt ? box_area(lo, hi) : 0;
+                right_n[k] = cnt;
+            }
+            lo = big; hi = small; cnt = 0;
+            for (int k = 0; k + 1 < kBins; ++k) {
+                grow(lo, hi, blo[k], bhi[k]);
+                cnt += bn[k];
+                if (cnt == 0 || right_n[k + 1] == 0) continue;
+                const double cost = box_area(lo, hi) * cnt + right_area[k + 1] * right_n[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_k = k; }
+            }
+        }
+        int mid = b + (e - b) / 2;
+        if (best_axis >= 0) {
+            const double lo = axis_of(clo, best_axis), scale = kBins / (axis_of(chi, best_axis) - lo);
+            std::vector<SahShape> left, right;
+            for (int i = b; i < e; ++i)
+                (bin_of(axis_of(shp[i].c, best_axis), lo, scale) <= best_k ? left : right).push_back(shp[i]);
+            mid = b + (int)left.size();
+            std::copy(left.begin(), left.end(), shp.begin() + b);
+            std::copy(right.begin(), right.end(), shp.begin() + mid);
+        }
+        const int l = split(b, mid);
+        const int r = split(mid, e);
+        nodes[(size_t)me].left = l; nodes[(size_t)me].right = r;
+        return me;
+    }
+    Node* make(const V3<double>& lo, const V3<double>& hi) {
+        sc.pool.emplace_back(new Node());
+        Node* n = sc.pool.back().get();
+        n->pmin = lo; n->pmax = hi;
+        return n;
+    }
+    Node* widen(int at) {
+        const SahSplit nd = nodes[(size_t)at];
+        Node* out = make(nd.lo, nd.hi);
+        out->leaf = false; out->has_children = true;
+        if (nd.left < 0) {
+            for (int i = nd.b; i < nd.e; ++i) {
+                Node* c = make(shp[i].lo, shp[i].hi);
+                c->leaf = true; c->shape = shp[i].shape;
+                out->children[i - nd.b] = c;
+            }
+            return out;
+        }
+        std::vector<int> kids{nd.left, nd.right};
+        while (kids.size() < 8) {
+            int pick = -1;
+            double pick_area = -1;
+            for (size_t i = 0; i < kids.size(); ++i) {
+                const SahSplit& k = nodes[(size_t)kids[i]];
+                if (k.left < 0) continue;
+                const double a = box_area(k.lo, k.hi);
+                if (a > pick_area) { pick_area = a; pick = (int)i; }
+            }
+            if (pick < 0) break;
+            const SahSplit k = nodes[(size_t)kids[(size_t)pick]];
+            kids[(size_t)pick] = k.left;
+            kids.push_back(k.right);
+        }
+        const V3<double> m{(nd.lo.x + nd.hi.x) * 0.5, (nd.lo.y + nd.hi.y) * 0.5, (nd.lo.z + nd.hi.z) * 0.5};
+        int slot_of[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+        std::vector<char> placed(kids.size(), 0);
+        for (size_t round = 0; round < kids.size(); ++round) {
+            int bi = -1, bs = -1;
+            double bscore = 0;
+            for (size_t i = 0; i < kids.size(); ++i) {
+                if (placed[i]) continue;
+                const SahSplit& k = nodes[(size_t)kids[i]];
+                const V3<double> ctr{(k.lo.x + k.hi.x) * 0.5, (k.lo.y + k.hi.y) * 0.5, (k.lo.z + k.hi.z) * 0.5};
+                for (int sl = 0; sl < 8; ++sl) {
+                    if (slot_of[sl] >= 0) continue;
+                    double score = 0;
+                    score += ((sl & 1) ? 1.0 : -1.0) * (ctr.x - m.x);
+                    score += ((sl & 2) ? 1.0 : -1.0) * (ctr.y - m.y);
+                    score += ((sl & 4) ? 1.0 : -1.0) * (ctr.z - m.z);
+                    if (bi < 0 || score > bscore) { bi = (int)i; bs = sl; bscore = score; }
+                }
+            }
+            slot_of[bs] = kids[(size_t)bi];
+            placed[(size_t)bi] = 1;
+        }
+        for (int sl = 0; sl < 8; ++sl)
+            if (slot_of[sl] >= 0) out->children[sl] = widen(slot_of[sl]);
+        return out;
+    }
+};
+void fill_f32_boxes(Node* n);
+Node* build_wide_tree(Scene& sc, int leaf_size) {
+    const int n = (int)sc.t64.shapes.size();
+    if (n == 0) return nullptr;
+    SahTree t{sc, leaf_size < 1 ? 1 : (leaf_size > 8 ? 8 : leaf_size), {}, {}};
+    t.shp.resize((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        SahShape& s = t.shp[(size_t)i];
+        shape_bounds(sc.t64.shapes[(size_t)i], s.lo, s.hi);
+        s.c = {(s.lo.x + s.hi.x) * 0.5, (s.lo.y + s.hi.y) * 0.5, (s.lo.z + s.hi.z) * 0.5};
+        s.shape = i;
+    }
+    t.split(0, n);
+    Node* root = t.widen(0);
+    fill_f32_boxes(root);
+    return root;
 }
 
 // ------------------------------------------------------------------------------------
@@ -647,7 +815,7 @@ bool trace_stack_f32(const Scene& sc, const Ray<float>& r, float tmin, float tma
     Hit<float> hr{any_hit ? tmax : FLT_MAX, {}, {}, -1};
     bool found = false;
     std::vector<Node*> stack;
-    Node* root = effective(sc.root);
+    Node* root = effective(sc.tree_kind == 1 && sc.wide_root ? sc.wide_root : sc.root);
     const int leaf_size = sc.leaf_size < 1 ? 1 : sc.leaf_size;
     Node fake;  // a root that is itself one leaf gets a synthetic one-child parent, as in the device flattener
     if (root->count <= leaf_size) {
@@ -1090,6 +1258,8 @@ orc_scene* orc_scene_create(const rt_scene_desc* d) {
     b.build();
     fill_f32_boxes(sc.root);
     build_blocks(sc.root, sc.leaf_size);
+    sc.wide_root = build_wide_tree(sc, sc.leaf_size);
+    if (sc.wide_root) build_blocks(sc.wide_root, sc.leaf_size);
     return o;
 }
 void orc_scene_destroy(orc_scene* s) { delete s; }
@@ -1097,7 +1267,11 @@ void orc_scene_destroy(orc_scene* s) { delete s; }
 void orc_set_leaf_size(orc_scene* s, int leaf_size) {
     s->sc.leaf_size = leaf_size < 1 ? 1 : leaf_size;
     build_blocks(s->sc.root, s->sc.leaf_size);
+    s->sc.wide_root = build_wide_tree(s->sc, s->sc.leaf_size);  // the SAH leaves depend on leaf_size
+    if (s->sc.wide_root) build_blocks(s->sc.wide_root, s->sc.leaf_size);
 }
+// F32_STACK only: which device tree to mirror (RTGO_TREE): 1 = binned SAH (default), 0 = the reference's octree
+void orc_set_tree(orc_scene* s, int kind) { s->sc.tree_kind = kind; }
 
 // out[0] = pointer-tree node count, out[1] = inner nodes (non-leaf, after prune), out[2] = max depth
 void orc_tree_info(const orc_scene* s, int64_t* out) {

@@ -3,6 +3,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <algorithm>
 #include <cstdlib>
 #include <deque>
 
@@ -166,6 +167,158 @@ std::vector<HostNode> build_octree(const rt_shape* shapes, int64_t n) {
         }
     }
     return nodes;
+}
+
+// ---- binned-SAH BVH emitted in the same 8-slot HostNode form (the default tree; spec in octree.hpp) ----
+namespace {
+struct SahItem { double lo[3], hi[3], c[3]; int32_t shape; };
+struct Bvh2 { double lo[3], hi[3]; int32_t left = -1, right = -1, b = 0, e = 0; };
+double area3(const double lo[3], const double hi[3]) {
+    const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return 2.0 * ((dx * dy + dy * dz) + dz * dx);
+}
+struct SahBuilder {
+    std::vector<SahItem> items;
+    std::vector<Bvh2> b2;
+    int leaf_size;
+    int32_t build(int32_t b, int32_t e) {
+        Bvh2 nd;
+        nd.b = b; nd.e = e;
+        double clo[3], chi[3];
+        for (int a = 0; a < 3; ++a) { nd.lo[a] = clo[a] = DBL_MAX; nd.hi[a] = chi[a] = -DBL_MAX; }
+        for (int32_t i = b; i < e; ++i)
+            for (int a = 0; a < 3; ++a) {
+                nd.lo[a] = std::fmin(nd.lo[a], items[i].lo[a]); nd.hi[a] = std::fmax(nd.hi[a], items[i].hi[a]);
+                clo[a] = std::fmin(clo[a], items[i].c[a]); chi[a] = std::fmax(chi[a], items[i].c[a]);
+            }
+        const int32_t me = (int32_t)b2.size();
+        b2.push_back(nd);
+        if (e - b <= leaf_size) return me;
+        constexpr int kBins = 16;
+        int best_axis = -1, best_split = 0;
+        double best_cost = DBL_MAX;
+        for (int a = 0; a < 3; ++a) {
+            const double ext = chi[a] - clo[a];
+            if (!(ext > 0)) continue;
+            struct Bin { double lo[3], hi[3]; int n; } bins[kBins];
+            for (auto& bn : bins) { bn.n = 0; for (int k = 0; k < 3; ++k) { bn.lo[k] = DBL_MAX; bn.hi[k] = -DBL_MAX; } }
+            const double scale = kBins / ext;
+            for (int32_t i = b; i < e; ++i) {
+                int k = (int)((items[i].c[a] - clo[a]) * scale);
+                if (k >= kBins) k = kBins - 1;
+                bins[k].n++;
+                for (int q = 0; q < 3; ++q) { bins[k].lo[q] = std::fmin(bins[k].lo[q], items[i].lo[q]); bins[k].hi[q] = std::fmax(bins[k].hi[q], items[i].hi[q]); }
+            }
+            double ra[kBins]; int rn[kBins];
+            double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+            int cnt = 0;
+            for (int k = kBins - 1; k >= 1; --k) {
+                for (int q = 0; q < 3; ++q) { lo[q] = std::fmin(lo[q], bins[k].lo[q]); hi[q] = std::fmax(hi[q], bins[k].hi[q]); }
+                cnt += bins[k].n;
+                ra[k] = cnt ? area3(lo, hi) : 0; rn[k] = cnt;
+            }
+            for (int q = 0; q < 3; ++q) { lo[q] = DBL_MAX; hi[q] = -DBL_MAX; }
+            cnt = 0;
+            for (int k = 0; k < kBins - 1; ++k) {
+                for (int q = 0; q < 3; ++q) { lo[q] = std::fmin(lo[q], bins[k].lo[q]); hi[q] = std::fmax(hi[q], bins[k].hi[q]); }
+                cnt += bins[k].n;
+                if (cnt == 0 || rn[k + 1] == 0) continue;
+                const double cost = area3(lo, hi) * cnt + ra[k + 1] * rn[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = k; }
+            }
+        }
+        int32_t mid;
+        if (best_axis < 0) {
+            mid = b + (e - b) / 2;  // all centroids coincide
+        } else {
+            const int a = best_axis;
+            const double scale = kBins / (chi[a] - clo[a]);
+            auto it = std::stable_partition(items.begin() + b, items.begin() + e, [&](const SahItem& s) {
+                int k = (int)((s.c[a] - clo[a]) * scale);
+                if (k >= kBins) k = kBins - 1;
+                return k <= best_split;
+            });
+            mid = (int32_t)(it - items.begin());
+            if (mid == b || mid == e) mid = b + (e - b) / 2;
+        }
+        const int32_t l = build(b, mid);
+        const int32_t r = build(mid, e);
+        b2[me].left = l; b2[me].right = r;
+        return me;
+    }
+    // wide node for Bvh2 node `n` written into HostNode `at`
+    void emit(std::vector<HostNode>& out, int32_t n, int32_t at) {
+        const Bvh2& nd = b2[n];
+        for (int a = 0; a < 3; ++a) { out[at].lo[a] = nd.lo[a]; out[at].hi[a] = nd.hi[a]; }
+        out[at].empty = false;
+        out[at].n_shapes = nd.e - nd.b;
+        out[at].shape = -1;
+        const int32_t base = (int32_t)out.size();
+        out[at].child_base = base;
+        out.resize(out.size() + 8);
+        if (nd.left < 0) {  // leaf: one single-shape child per shape
+            for (int32_t i = nd.b; i < nd.e; ++i) {
+                HostNode& c = out[base + (i - nd.b)];
+                for (int a = 0; a < 3; ++a) { c.lo[a] = items[i].lo[a]; c.hi[a] = items[i].hi[a]; }
+                c.shape = items[i].shape; c.empty = false; c.n_shapes = 1;
+            }
+            return;
+        }
+        int32_t kids[8]; int nk = 2;
+        kids[0] = nd.left; kids[1] = nd.right;
+        while (nk < 8) {
+            int pick = -1; double pa = -1;
+            for (int i = 0; i < nk; ++i) {
+                if (b2[kids[i]].left < 0) continue;
+                const double ar = area3(b2[kids[i]].lo, b2[kids[i]].hi);
+                if (ar > pa) { pa = ar; pick = i; }
+            }
+            if (pick < 0) break;
+            const int32_t k = kids[pick];
+            kids[pick] = b2[k].left;
+            kids[nk++] = b2[k].right;
+        }
+        double m[3];
+        for (int a = 0; a < 3; ++a) m[a] = (nd.lo[a] + nd.hi[a]) * 0.5;
+        int32_t slot[8]; for (int& x : slot) x = -1;
+        bool placed[8] = {};
+        for (int round = 0; round < nk; ++round) {
+            int bi = -1, bs = -1; double bsc = 0;
+            for (int i = 0; i < nk; ++i) {
+                if (placed[i]) continue;
+                const Bvh2& c = b2[kids[i]];
+                for (int sl = 0; sl < 8; ++sl) {
+                    if (slot[sl] >= 0) continue;
+                    double sc = 0;
+                    for (int a = 0; a < 3; ++a) sc += ((sl >> a) & 1 ? 1.0 : -1.0) * ((c.lo[a] + c.hi[a]) * 0.5 - m[a]);
+                    if (bi < 0 || sc > bsc) { bi = i; bs = sl; bsc = sc; }
+                }
+            }
+            slot[bs] = kids[bi]; placed[bi] = true;
+        }
+        for (int sl = 0; sl < 8; ++sl)
+            if (slot[sl] >= 0) emit(out, slot[sl], base + sl);
+    }
+};
+}  // namespace
+
+std::vector<HostNode> build_sah(const rt_shape* shapes, int64_t n, int leaf_size) {
+    std::vector<HostNode> out;
+    if (n == 0) { out.push_back(HostNode{}); return out; }
+    SahBuilder sb;
+    sb.leaf_size = leaf_size < 1 ? 1 : (leaf_size > 8 ? 8 : leaf_size);
+    sb.items.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        SahItem& it = sb.items[(size_t)i];
+        shape_bounds(shapes[i], it.lo, it.hi);
+        for (int a = 0; a < 3; ++a) it.c[a] = (it.lo[a] + it.hi[a]) * 0.5;
+        it.shape = (int32_t)i;
+    }
+    sb.build(0, (int32_t)n);
+    out.reserve((size_t)n * 3);
+    out.push_back(HostNode{});
+    sb.emit(out, 0, 0);
+    return out;
 }
 
 // depth-first, octant order

@@ -55,6 +55,20 @@ struct FlatTree {
 
 // shapes: desc->shapes[0..n). Returns nodes[0] = root.
 std::vector<HostNode> build_octree(const rt_shape* shapes, int64_t n);
+// The default tree ("faster builder"): a binned-SAH BVH in the same 8-slot node form, so
+// that flatten_octree() and the traversal are shared with the reference's octree (RTGO_TREE=octree).
+//   split(range): boxes and centroid bounds (centroid = centre of the shape's box); at most leaf_size
+//     (<= 8) shapes -> leaf.  Otherwise, per axis with a positive centroid extent, 16 equal bins;
+//     for every bin boundary with shapes on both sides cost = area(left) * n_left + area(right) *
+//     n_right; strictly smallest cost wins (first axis / boundary on ties); the range is split stably;
+//     with no valid boundary, in the middle.
+//   widen(node): children = {left, right}; while fewer than 8 and some child is inner, the inner child
+//     with the largest area (first on ties) is replaced by its left child, its right child appended;
+//     children take slots by the greedy octant matching of block_slots.  A leaf's shapes become
+//     single-shape children in slots 0.. in range order.
+// Any tree whose boxes enclose their shapes gives the same hits; only the order in which equal-t hits
+// are found depends on it, which is why the oracle's fp32 mode restates this builder too.
+std::vector<HostNode> build_sah(const rt_shape* shapes, int64_t n, int leaf_size);
 // Returns false (and sets *err) if the tree exceeds kMaxChildRecords.
 bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree* out, const char** err);
 

@@ -33,6 +33,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kMaxGridBlocks = 2048;  // 256 CUs x 8: persistent grid-stride kernels
 constexpr int64_t kDefaultMaxPaths = (int64_t)1 << 23;
+constexpr int kDefaultLeafSizeSah = 6;  // measured on config 3 (k_shadow ms per frame): 2 -> 833, 3 -> 816, 4 -> 823, 6 -> 791, 8 -> 809
 constexpr int kDefaultLeafSize = 4;  // measured on config 3: 1 -> 2.84 s, 2 -> 2.58 s, 4 -> 2.42 s, 8 -> 2.48 s, 16 -> 2.76 s per frame
 
 thread_local std::string g_err;
@@ -614,11 +615,16 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     const auto t0 = std::chrono::steady_clock::now();
     FlatTree flat;
     {
-        const std::vector<HostNode> nodes = build_octree(desc->shapes, desc->n_shapes);
         const char* err = nullptr;
         // shapes per leaf: 1 = the reference's tree; larger leaves trade box tests for shape tests
         const char* ls = std::getenv("RTGO_LEAF_SIZE");
-        const int leaf_size = ls ? std::atoi(ls) : kDefaultLeafSize;
+        const char* tree = std::getenv("RTGO_TREE");
+        const bool octree = tree && std::strcmp(tree, "octree") == 0;
+        const int leaf_size = ls ? std::atoi(ls) : (octree ? kDefaultLeafSize : kDefaultLeafSizeSah);
+        // default: binned-SAH tree (octree.hpp); RTGO_TREE=octree builds the reference's insertion octree
+        const std::vector<HostNode> nodes = octree
+                                                ? build_octree(desc->shapes, desc->n_shapes)
+                                                : build_sah(desc->shapes, desc->n_shapes, leaf_size);
         if (!flatten_octree(nodes, leaf_size, &flat, &err)) return fail(RT_ERR_LIMIT, err);
     }
     // shapes -> 3 float4 each, narrowed to fp32 (round to nearest), stored in leaf order

@@ -88,9 +88,12 @@ def test_primary_hit_ids_bit_exact_c1(dev_c1, orc_c1, c1, bridge):
     assert set(np.unique(gp)) <= set(range(-1, 11))
 
 
-def test_secondary_and_shadow_rays_bit_exact(backend, bridge, rt, scenes):
+@pytest.mark.parametrize("tree", ["sah", "octree"])
+def test_secondary_and_shadow_rays_bit_exact(backend, bridge, rt, scenes, tree, monkeypatch):
     """Mirror-bounce secondary rays (non-unit directions, origins on surfaces) and any-hit shadow rays
-    on a 5k-triangle mesh scene."""
+    on a 5k-triangle mesh scene, through the default binned-SAH tree and through the reference's octree
+    (RTGO_TREE is read when the device scene / the oracle mirror is created)."""
+    monkeypatch.setenv("RTGO_TREE", tree)
     spec, scene = _mesh_scene(rt, scenes)
     with backend.DeviceScene(scene) as dev, bridge.OracleScene(scene) as osc:
         px = _rand_pixels(spec, 30000, 2)
@@ -283,10 +286,12 @@ def test_soft_shadow_repetition_counts(backend, bridge, rt):
         assert close.mean() > 0.995, close.mean()
 
 
-def test_deep_tree_uses_stack_spill(backend, bridge, rt):
+@pytest.mark.parametrize("tree", ["octree", "sah"])
+def test_deep_tree_uses_stack_spill(backend, bridge, rt, tree, monkeypatch):
     """Nearly coincident centroids make the octree recurse until the 1e-10 jitter separates them
     (accelerationstructures.go:265-279); single-child chains are dropped by the flattener and the
     traversal stack may exceed its LDS part.  Results still match the oracle bit for bit."""
+    monkeypatch.setenv("RTGO_TREE", tree)
     V = rt.Vec
     rng = np.random.default_rng(4)
     shapes = []
