@@ -825,7 +825,7 @@ bool trace_stack_f32(const Scene& sc, const Ray<float>& r, float tmin, float tma
     }
     std::vector<int> group;
     Node* cur = root;
-    const float t0 = 0.0f;
+    const float t0 = any_hit ? tmin : 0.0f;  // device: shadow rays clip the slab test to [tmin, tmax]
     for (;;) {
         if (tc) tc->inner++;
         Node* pending[8]; int np = 0;

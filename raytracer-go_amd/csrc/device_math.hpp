@@ -229,7 +229,7 @@ RT_DEV TraceRay make_trace_ray(f3 o, f3 d) {
 }
 
 // (1): slab tests of the 8 slots of block `cur` in ray order; bit k of the masks = ray-order position k
-RT_DEV void visit_block(const DScene& S, uint32_t cur, const TraceRay& r, float entry_best, uint32_t ref[8],
+RT_DEV void visit_block(const DScene& S, uint32_t cur, const TraceRay& r, float t_enter, float entry_best, uint32_t ref[8],
                         uint32_t* leaf_mask, uint32_t* inner_mask) {
     RT_PROF_POINT(0);  // block visits
     const uint32_t first = cur >> 8, present = cur & 0xffu;
@@ -249,7 +249,7 @@ RT_DEV void visit_block(const DScene& S, uint32_t cur, const TraceRay& r, float 
     for (int k = 0; k < 8; ++k) {  // no branch per slot: an absent slot's result is masked out
         const uint32_t oct = (uint32_t)k ^ r.sign;
         const float4 a = ra[k], b = rb[k];
-        float tn = 0.0f, tf = entry_best;
+        float tn = t_enter, tf = entry_best;
         {
             const float lo = fmaf(a.x, r.inv.x, -r.oi.x), hi = fmaf(a.w, r.inv.x, -r.oi.x);
             tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
@@ -351,7 +351,7 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
     for (;;) {
         uint32_t ref[8];
         uint32_t leaf_mask = 0, inner_mask = 0;
-        if (walking) visit_block(S, cur, r, best, ref, &leaf_mask, &inner_mask);
+        if (walking) visit_block(S, cur, r, 0.0f, best, ref, &leaf_mask, &inner_mask);
         // room for this visit's leaves in every lane's queue?
         if (__ballot(npend + (uint32_t)__popc(leaf_mask) > (uint32_t)kPendCap) != 0ull) flush();
         queue_leaves(pend, st.lds_stride, ref, leaf_mask, &npend);
@@ -400,7 +400,7 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
     for (;;) {
         uint32_t ref[8];
         uint32_t leaf_mask = 0, inner_mask = 0;
-        if (walking) visit_block(S, cur, r, tmax, ref, &leaf_mask, &inner_mask);
+        if (walking) visit_block(S, cur, r, tmin, tmax, ref, &leaf_mask, &inner_mask);  // a box that ends before tmin holds no accepted hit
         if (__ballot(npend + (uint32_t)__popc(leaf_mask) > (uint32_t)kPendCap) != 0ull) {
             flush();
             if (occ) break;

@@ -78,6 +78,7 @@ struct Work {
     float4* ray_d;   // {direction.xyz, bits of hit shape index (-1 = miss)}
     float4* thr;     // path throughput (product of attenuations)
     float4* rad;     // terminal radiance of the path (written once)
+    uint2* path_key; // {pixel index, sample index} of the path: the Philox counter words every later draw needs
     uint32_t* queue[2];
     uint32_t* phong_queue;
     uint32_t* vis;   // visible-repetition count per (phong hit, positional light)
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(Batch B, DCamera cam, Work Wk
     }
     if (valid) {
         const RngKey key{B.k0, B.k1, (uint32_t)(row * B.W + x), (uint32_t)smp};
+        Wk.path_key[slot] = make_uint2(key.pixel, key.sample);
         f3 o, d;
         camera_ray(cam, B.W, B.H, x, B.H - 1 - row, key, &o, &d);
         Wk.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.0f);
@@ -186,10 +188,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, Batch B, Work Wk, co
                 phong = true;
             } else {
                 const f3 nrm = prim_normal(P, o, d, t);
-                const long long lpl = (long long)slot / B.ns;
-                int x, row;
-                pixel_of(B, B.lp0 + lpl, &x, &row);
-                const RngKey key{B.k0, B.k1, (uint32_t)(row * B.W + x), (uint32_t)(B.s0 + (int)(slot - lpl * B.ns))};
+                const uint2 pk = Wk.path_key[slot];
+                const RngKey key{B.k0, B.k1, pk.x, pk.y};
                 if (m.kind == RT_MAT_METAL) {  // material.go:43-50
                     const float fuzz = m.param < 1.0f ? m.param : 1.0f;
                     const f3 refl = reflected(d, nrm);
@@ -345,10 +345,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_shadow(DScene S, Batch B, Work Wk
                 const uint32_t slot = Wk.phong_queue[hit_i];
                 const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
                 p = add3(mk3(ro.x, ro.y, ro.z), scale3(ro.w, mk3(rdv.x, rdv.y, rdv.z)));
-                const uint32_t lpl = slot / (uint32_t)B.ns;
-                int x, row;
-                pixel_of(B, B.lp0 + lpl, &x, &row);
-                const RngKey key{B.k0, B.k1, (uint32_t)(row * B.W + x), (uint32_t)B.s0 + (slot - lpl * (uint32_t)B.ns)};
+                const uint2 pk = Wk.path_key[slot];
+                const RngKey key{B.k0, B.k1, pk.x, pk.y};
                 int q = 0;  // positional light #lp
                 for (int seen = -1; q < S.n_lights; ++q)
                     if (S.lights[q].kind != RT_LIGHT_AMBIENT && ++seen == (int)lp) break;
@@ -488,7 +486,7 @@ namespace {
 
 void free_work(rt_scene* s) {
     Work& w = s->wk;
-    void* ptrs[] = {w.ray_o, w.ray_d, w.thr, w.rad, w.queue[0], w.queue[1], w.phong_queue, w.vis, w.pairs, w.pair_seg, w.light_count, w.counters};
+    void* ptrs[] = {w.ray_o, w.ray_d, w.thr, w.rad, w.path_key, w.queue[0], w.queue[1], w.phong_queue, w.vis, w.pairs, w.pair_seg, w.light_count, w.counters};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     uint32_t* ov = w.overflow; const uint32_t os = w.overflow_stride;
     w = Work{};
@@ -504,6 +502,7 @@ int ensure_work(rt_scene* s, int64_t paths, int depth, int lpos) {
     HIP_TRY(hipMalloc((void**)&w.ray_d, paths * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&w.thr, paths * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&w.rad, paths * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&w.path_key, paths * sizeof(uint2)));
     HIP_TRY(hipMalloc((void**)&w.queue[0], paths * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w.queue[1], paths * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&w.phong_queue, paths * sizeof(uint32_t)));
