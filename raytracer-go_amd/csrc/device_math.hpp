@@ -194,12 +194,15 @@ __device__ unsigned long long g_prof[8];  // [2i] = times a wavefront passed poi
 // a leaf in the current block ran at 16 % lane utilisation and was half the kernel's instructions.
 // Holding a leaf back cannot change the result: a lane's shapes are still tested in the same order,
 // and a box that a smaller `best` would have culled holds no hit below that `best`.
-constexpr int kLdsStackDepth = 24;
+#ifndef RTGO_LDS_STACK
+#define RTGO_LDS_STACK 20
+#endif
+constexpr int kLdsStackDepth = RTGO_LDS_STACK;
 #ifndef RTGO_PEND_CAP
-#define RTGO_PEND_CAP 12
+#define RTGO_PEND_CAP 16
 #endif
 #ifndef RTGO_FLUSH_LANES
-#define RTGO_FLUSH_LANES 48
+#define RTGO_FLUSH_LANES 64
 #endif
 constexpr int kPendCap = RTGO_PEND_CAP;        // leaves a lane can hold back (one block visit adds at most 8)
 constexpr int kFlushLanes = RTGO_FLUSH_LANES;  // run the shape loop when this many lanes hold leaves
