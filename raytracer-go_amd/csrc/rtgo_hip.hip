@@ -265,9 +265,29 @@ RT_DEV PhongHit load_phong_hit(const DScene& S, const Work& Wk, uint32_t slot) {
     return h;
 }
 
+// True only if the spot-cone test of k_shadow (light.go:126-130) fails for EVERY jittered light position:
+// the jitter moves the light by less than 0.25, which turns the direction light -> p by at most
+// asin(0.25 / |p - L|); a point whose angle to the cone axis exceeds Angle by more than that (plus a
+// margin far above fp32 rounding) is outside the cone for all repetitions, so the pair has no ray to trace.
+RT_DEV bool surely_outside_cone(const DLight& L, const f3& p) {
+    if (L.kind != RT_LIGHT_SPOT) return false;
+    const f3 v = sub3(p, ld3(L.pos));
+    const float dist = norm3(v);
+    const float sin_d = 0.25f / dist * 1.001f + 1e-4f;  // NaN / Inf for dist = 0 fail the next test
+    if (!(sin_d < 0.99f)) return false;
+    const float cos_d = sqrtf(1.0f - sin_d * sin_d);
+    const float cos_a = L.cos_angle;
+    const float sin_a = sqrtf(fmaxf(0.0f, 1.0f - cos_a * cos_a));  // Angle in [0, 180] degrees
+    if (!(sin_a * cos_d + cos_a * sin_d > 1e-3f)) return false;     // Angle + delta must stay below 180 degrees
+    const float cos_limit = cos_a * cos_d - sin_a * sin_d;          // cos(Angle + delta)
+    const float cos_p = dot3(ld3(L.look_dir), scale3(1.0f / dist, v));
+    return cos_p < cos_limit - 1e-4f;
+}
+
 // One lane per PhongBlinn hit.  A (hit, light) pair whose shading term is exactly (0,0,0) — light behind
 // the surface and no specular lobe towards it — adds count/reps * 0 whatever its soft-shadow rays would
-// find, so those rays are never generated: only the other pairs are queued for k_shadow, per light
+// find, so those rays are never generated; nor are those of a pair that lies outside a spot light's cone
+// for every jittered light position.  Only the other pairs are queued for k_shadow, per light
 // (segment l of pair_seg), so that the queue k_pair_compact builds from the segments is light-major.
 // Every pair's visible-repetition count starts at 0 here.
 __global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, uint32_t n_hits) {
@@ -281,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, uint3
         bool keep = false;
         if (live) {
             const f3 comb = phong_term(S.lights[q], h.m, h.mc, h.p, h.nrm, h.d);
-            keep = !(comb.x == 0.0f && comb.y == 0.0f && comb.z == 0.0f);
+            keep = !(comb.x == 0.0f && comb.y == 0.0f && comb.z == 0.0f) && !surely_outside_cone(S.lights[q], h.p);
             Wk.vis[(size_t)hit_i * S.n_pos_lights + lp] = 0u;
         }
         const uint32_t at = wave_push(&Wk.light_count[lp], keep);
