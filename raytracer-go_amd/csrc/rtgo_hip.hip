@@ -91,16 +91,27 @@ struct Work {
     uint32_t overflow_stride;
 };
 
-// ballot + popcount-prefix compaction: one atomic per wavefront
-RT_DEV uint32_t wave_push(uint32_t* counter, bool pred) {
+// Queue compaction: ballot + popcount prefix inside a wavefront, the wavefronts' counts combined through
+// LDS, ONE atomic per 256-thread block (a queue counter is a single address: with one atomic per
+// wavefront the 131k same-address atomics of a batch took longer than the kernels' real work).
+// Every thread of the block must call it.
+RT_DEV uint32_t block_push(uint32_t* counter, bool pred) {
+    __shared__ uint32_t s_cnt[kBlock / 64 + 1];
     const unsigned long long mask = __ballot(pred);
-    if (mask == 0ull) return 0u;
-    const int lane = (int)__lane_id();
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = (uint32_t)__shfl((int)base, leader);
-    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const int lane = (int)__lane_id(), wave = (int)(threadIdx.x >> 6);
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < kBlock / 64; ++w) total += s_cnt[w];
+        s_cnt[kBlock / 64] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t at = s_cnt[kBlock / 64];
+    for (int w = 0; w < wave; ++w) at += s_cnt[w];
+    at += (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    __syncthreads();  // s_cnt is reused by the next call
+    return at;
 }
 
 // raytracer.go:114-116 + camera.go:37-55
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(Batch B, DCamera cam, Work Wk
         Wk.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
     }
     if (slot < total) Wk.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const uint32_t at = wave_push(&Wk.counters[0], valid);
+    const uint32_t at = block_push(&Wk.counters[0], valid);
     if (valid) Wk.queue[0][at] = (uint32_t)slot;
 }
 
@@ -223,9 +234,9 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, Batch B, Work Wk, co
     }
     // a ray scattered at the last allowed depth can only return black (raytracer.go:145)
     cont = cont && (bounce + 1 < B.max_depth);
-    const uint32_t at = wave_push(&Wk.counters[bounce + 1], cont);
+    const uint32_t at = block_push(&Wk.counters[bounce + 1], cont);
     if (cont) next_queue[at] = slot;
-    const uint32_t pat = wave_push(&Wk.counters[B.max_depth + 1 + bounce], phong);
+    const uint32_t pat = block_push(&Wk.counters[B.max_depth + 1 + bounce], phong);
     if (phong) Wk.phong_queue[pat] = slot;
 }
 
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, uint3
     PhongHit h{};
     if (live) h = load_phong_hit(S, Wk, Wk.phong_queue[hit_i]);
     uint32_t lp = 0;
-    for (int q = 0; q < S.n_lights; ++q) {  // uniform trip count: wave_push is a wavefront operation
+    for (int q = 0; q < S.n_lights; ++q) {  // uniform trip count: block_push is a block-wide operation
         if (S.lights[q].kind == RT_LIGHT_AMBIENT) continue;
         bool keep = false;
         if (live) {
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, uint3
             keep = !(comb.x == 0.0f && comb.y == 0.0f && comb.z == 0.0f) && !surely_outside_cone(S.lights[q], h.p);
             Wk.vis[(size_t)hit_i * S.n_pos_lights + lp] = 0u;
         }
-        const uint32_t at = wave_push(&Wk.light_count[lp], keep);
+        const uint32_t at = block_push(&Wk.light_count[lp], keep);
         if (keep) Wk.pair_seg[(size_t)lp * n_hits + at] = hit_i;
         ++lp;
     }
