@@ -136,12 +136,19 @@ def main():
         achieved = shadow_bytes / world / shadow_s / 1e9 if shadow_s > 0 else 0.0
         extend_bytes = n_prim * bray["primary"]["bytes_per_ray"] + n_cont * bray["continuation"]["bytes_per_ray"]
         traffic = None  # HBM-side bytes per k_shadow launch, from the committed rocprofv3 PMC passes of this same workload
+        issue = None    # the same passes' VALU figures: what actually bounds the kernel
         tpath = os.path.join(ROOT, "profiles", "r01", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             if tj["workload"] == {"width": W, "height": H, "spp": spec.AntiAliasingFactor, "config": "config3"}:
                 traffic = tj["hbm_bytes_per_launch"]
+                isu = tj.get("issue")
+                if isu and shadow_s > 0 and world == 1:
+                    issue = {"valu_insts_per_ray": isu["valu_insts_per_frame"] / (n_shadow / args.steps),
+                             "valu_active_lane_frac": isu["valu_active_lane_frac"],
+                             "valu_busy_frac_profiled": isu["valu_busy_seconds_per_frame"] / (shadow_s / args.steps),
+                             "source": "profiles/r01/f_final_pmc.txt"}
         out = {
             "metric": "Mrays/s (whole node), Stanford Dragon 1080p 64spp",
             "value": rays / elapsed / 1e6,
@@ -163,7 +170,7 @@ def main():
                                     "shade_phong_other": ms_shade / args.steps / world},
             "roofline": {"bound": "hbm", "kernel": "k_shadow", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_ray": bray["shadow"]["bytes_per_ray"],
+                         "bytes_per_ray": bray["shadow"]["bytes_per_ray"], "issue_bound": issue,
                          "k_extend_achieved": (extend_bytes / world / (ms_extend / 1e3 / world) / 1e9) if ms_extend > 0 else 0.0},
         }
         if world == 1 and not args.no_cpu_baseline:
