@@ -88,6 +88,37 @@ def test_primary_hit_ids_bit_exact_c1(dev_c1, orc_c1, c1, bridge):
     assert set(np.unique(gp)) <= set(range(-1, 11))
 
 
+def test_device_matches_committed_vectors(dev_c1, c1, gold_dir):
+    """Expected values that need no oracle at run time: tests/golden/c1_vectors.npz holds the reference-faithful
+    (float64, best-first, reference octree) hits of config 1.  The device (fp32, SAH tree) must return the same
+    shapes: 0 differing pixels of the full 640x380 frame (SHA-256 of the shape-index table), the same t to fp32
+    accuracy, and the same mirror-bounce hits up to the few rays whose fp32-rounded origin on a surface decides
+    self-intersection differently."""
+    import hashlib
+    import os
+
+    v = np.load(os.path.join(gold_dir, "c1_vectors.npz"))
+    spec = c1[0]
+    rays = np.zeros((v["rays"].shape[0], 8), np.float32)
+    rays[:, :6] = v["rays"]
+    gp, gt = dev_c1.trace_rays(rays)
+    assert (gp != v["prim"]).sum() <= 1
+    hit = (gp >= 0) & (gp == v["prim"])
+    assert np.abs(gt[hit] / v["t"][hit] - 1).max() < 1e-4
+    sec = np.zeros((v["metal_secondary_rays"].shape[0], 8), np.float32)
+    sec[:, :6] = v["metal_secondary_rays"]
+    sp, _ = dev_c1.trace_rays(sec)
+    mism = (sp != v["metal_secondary_prim"]).mean()
+    print(f"mirror-bounce IDs vs committed float64 vectors: {mism:.2e} differ")
+    assert mism < 1e-2
+    xs, ys = np.meshgrid(np.arange(spec.Width), np.arange(spec.Height))
+    px = np.stack([xs.ravel(), ys.ravel(), np.zeros(xs.size, int)], 1).astype(np.int32)
+    full = np.zeros((px.shape[0], 8), np.float32)
+    full[:, :6] = dev_c1.camera_rays(spec, px)
+    fp, _ = dev_c1.trace_rays(full)
+    assert hashlib.sha256(fp.astype("<i4").tobytes()).hexdigest() == str(v["full_ids_sha256"])
+
+
 @pytest.mark.parametrize("tree", ["sah", "octree"])
 def test_secondary_and_shadow_rays_bit_exact(backend, bridge, rt, scenes, tree, monkeypatch):
     """Mirror-bounce secondary rays (non-unit directions, origins on surfaces) and any-hit shadow rays

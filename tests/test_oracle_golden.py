@@ -120,3 +120,35 @@ def test_scatter_known_answers(bridge, rt):
     # Dielectric at normal incidence from outside (d.n < 0): ratio 1/RI; straight through or straight back, origin offset 1e-5*dir
     out = one(None, rt.TrianglePlane(V(-1, -1, 0), V(0, 1, 0), V(1, -1, 0), False, rt.Dielectric(RefractiveIndex=1.5)))
     assert out[0] == 1 and np.allclose(out[1:4], (1, 1, 1)) and abs(abs(out[9]) - 1) < 1e-9 and abs(out[6] - 1e-5 * out[9]) < 1e-12
+
+
+def test_oracle_reproduces_committed_vectors(bridge, c1, gold_dir):
+    """tests/golden/c1_vectors.npz (SURVEY 8c i-iii: primary hit table + full-frame hash, mirror-bounce
+    secondary hits, per-material scatter answers) was written by scripts/make_golden_vectors.py from the
+    float64 best-first mode; the oracle must still produce exactly that, whatever changes in its fp32
+    mirror of the device."""
+    import importlib.util
+    import os
+
+    spec_ = importlib.util.spec_from_file_location("make_golden_vectors", os.path.join(os.path.dirname(gold_dir), "..", "scripts", "make_golden_vectors.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    want = np.load(os.path.join(gold_dir, "c1_vectors.npz"))
+    spec, scene = c1
+    with bridge.OracleScene(scene) as osc:
+        got = mod.build(spec, osc)
+    assert str(got["full_ids_sha256"]) == str(want["full_ids_sha256"])
+    for k in ("pixels", "prim", "metal_index", "metal_secondary_prim"):
+        assert np.array_equal(got[k], want[k]), k
+    for k in ("rays", "t", "metal_secondary_rays", "metal_secondary_t", "scatter_probe_rays", "scatter_probe_out"):
+        assert np.allclose(got[k], want[k], rtol=1e-12, atol=1e-12), k
+    # reference semantics visible in the answers (material.go): Metal keeps the hit point as origin, Dielectric
+    # steps 1e-5 along the new direction, Standard / PhongBlinn do not continue
+    out, shapes = want["scatter_probe_out"], want["scatter_probe_rays"][:, 6].astype(int)
+    for row, shape in zip(out, shapes):
+        if shape in (3, 9, 10):      # Metal
+            assert row[0] == 1.0 and np.array_equal(row[4:7], row[14:17]) and np.allclose(row[1:4], 1.0)
+        elif shape == 1:             # Dielectric
+            assert row[0] == 1.0 and np.allclose(row[4:7], row[14:17] + 1e-5 * row[7:10], atol=1e-15)
+        else:                        # Standard, PhongBlinn: terminal colour
+            assert row[0] == 0.0 and (row[10:13] >= 0).all() and (row[10:13] <= 1.0001).all()
