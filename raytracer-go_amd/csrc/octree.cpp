@@ -204,8 +204,9 @@ struct SahBuilder {
             for (auto& bn : bins) { bn.n = 0; for (int k = 0; k < 3; ++k) { bn.lo[k] = DBL_MAX; bn.hi[k] = -DBL_MAX; } }
             const double scale = kBins / ext;
             for (int32_t i = b; i < e; ++i) {
-                int k = (int)((items[i].c[a] - clo[a]) * scale);
+                int k = (int)((items[i].c[a] - clo[a]) * scale);  // coordinates are finite (checked at scene creation)
                 if (k >= kBins) k = kBins - 1;
+                if (k < 0) k = 0;
                 bins[k].n++;
                 for (int q = 0; q < 3; ++q) { bins[k].lo[q] = std::fmin(bins[k].lo[q], items[i].lo[q]); bins[k].hi[q] = std::fmax(bins[k].hi[q], items[i].hi[q]); }
             }

@@ -622,10 +622,20 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         return fail(RT_ERR_INVALID, "negative table size");
     if (desc->n_shapes >= ((int64_t)1 << 28)) return fail(RT_ERR_LIMIT, "more than 2^28 shapes");
     if (desc->n_materials >= ((int64_t)1 << 30)) return fail(RT_ERR_LIMIT, "more than 2^30 materials");
+    if ((desc->n_shapes > 0 && !desc->shapes) || (desc->n_materials > 0 && !desc->materials) ||
+        (desc->n_textures > 0 && !desc->textures) || (desc->n_lights > 0 && !desc->lights))
+        return fail(RT_ERR_INVALID, "table pointer is NULL but its size is not 0");
+    // fp32 on the device: coordinates must be finite and well inside the float range
+    auto usable = [](const rt_vec3& v) {
+        return std::fabs(v.x) < 1e30 && std::fabs(v.y) < 1e30 && std::fabs(v.z) < 1e30;  // false for NaN / Inf too
+    };
     for (int64_t i = 0; i < desc->n_shapes; ++i) {
         const rt_shape& s = desc->shapes[i];
         if (s.kind != RT_SHAPE_SPHERE && s.kind != RT_SHAPE_TRIANGLE) return fail(RT_ERR_INVALID, "unknown shape kind");
         if (s.material < 0 || s.material >= desc->n_materials) return fail(RT_ERR_INVALID, "shape material index out of range");
+        // the reference's BVH build does not terminate on a NaN centroid (accelerationstructures.go:226-279)
+        if (!usable(s.a) || !(std::fabs(s.b.x) < 1e30) || (s.kind == RT_SHAPE_TRIANGLE && (!usable(s.b) || !usable(s.c))))
+            return fail(RT_ERR_INVALID, "shape " + std::to_string(i) + " has a non-finite (or > 1e30) coordinate");
     }
     for (int64_t i = 0; i < desc->n_materials; ++i) {
         const rt_material& m = desc->materials[i];

@@ -253,6 +253,13 @@ def test_error_behaviour(backend, dev_c1, c1, rt):
     bad = rt.Scene(Shapes=[rt.Sphere(rt.Vec(0, 0, 0), 1.0, object())])
     with pytest.raises(TypeError):
         backend.DeviceScene(bad)
+    # a NaN / Inf coordinate never leaves the reference's BVH build (the centroid cannot be placed): rejected here
+    mat = rt.Standard(ColorFrac=rt.Vec(1, 1, 1))
+    for shape in (rt.Sphere(rt.Vec(0, float("nan"), 0), 1.0, mat), rt.Sphere(rt.Vec(0, 0, 0), float("inf"), mat),
+                  rt.TrianglePlane(rt.Vec(0, 0, 0), rt.Vec(1, 0, 0), rt.Vec(0, float("inf"), 0), False, mat)):
+        with pytest.raises(backend.RtgoError) as e:
+            backend.DeviceScene(rt.Scene(Shapes=[rt.Sphere(rt.Vec(0, 0, 0), 1.0, mat), shape]))
+        assert e.value.code == rt._abi.RT_ERR_INVALID and "shape 1" in str(e.value)
 
 
 def test_edge_cases(backend, bridge, rt):
