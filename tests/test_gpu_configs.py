@@ -36,6 +36,33 @@ def test_config3_dragon_room(backend, bridge, scenes, gold_dir):
     assert st.rays_shadow < st.rays_shadow_reference_equivalent  # spot cones cull rays the reference would trace
 
 
+def test_full_size_result_does_not_depend_on_the_tree(backend, scenes, gold_dir, monkeypatch):
+    """Size-independent property at config 3's full 871,210 shapes: the default binned-SAH tree and the
+    reference's insertion octree (RTGO_TREE=octree) are two traversal orders over the same shapes, so hits,
+    ray counts and radiance agree — up to the order in which equal-t hits on shared edges are met."""
+    spec, scene = scenes.config3(320, 180, 2, 16, asset_dir=gold_dir)
+    rng = np.random.default_rng(21)
+    px = np.stack([rng.integers(0, spec.Width, 40000), rng.integers(0, spec.Height, 40000), rng.integers(0, 2, 40000)], 1).astype(np.int32)
+    out = {}
+    for tree in ("sah", "octree"):
+        monkeypatch.setenv("RTGO_TREE", tree)
+        with backend.DeviceScene(scene) as dev:
+            rays = np.zeros((px.shape[0], 8), np.float32)
+            rays[:, :6] = dev.camera_rays(spec, px)
+            ids, t = dev.trace_rays(rays)
+            acc, st = dev.render_accum(spec)
+            out[tree] = (ids, t, acc, st, dev.info())
+    (ia, ta, aa, sa, fa), (ib, tb, ab, sb, fb) = out["sah"], out["octree"]
+    assert fa["n_child_records"] < fb["n_child_records"] and fa["n_shapes"] == fb["n_shapes"] == 871210
+    differ = ia != ib
+    assert differ.mean() <= 1e-4 and np.array_equal(ta[~differ], tb[~differ])
+    if differ.any():  # a different shape only where both are hit at (nearly) the same t
+        assert np.abs(ta[differ] / tb[differ] - 1).max() < 1e-5
+    assert sa.rays_primary == sb.rays_primary and sa.phong_hits == sb.phong_hits
+    assert abs(int(sa.rays_shadow) - int(sb.rays_shadow)) <= 1e-5 * sa.rays_shadow
+    assert (np.abs(aa - ab).max(-1) > 1e-3).mean() <= 1e-4
+
+
 def test_config5_glass_metal_tiles(backend, bridge, scenes, rt, gold_dir):
     """config 5 content (Bunny + Dragon stand-ins, 6 Dielectric spheres, Metal floor, 4 SpotLights), reduced
     meshes; rendered whole and as a 2-rank tile split that must reassemble bit-exactly."""
