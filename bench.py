@@ -162,7 +162,7 @@ def main():
             "config": {"workload": "config3: Dragon stand-in (seeded torus-knot tube, 871,200 tris) in 10-tri room, "
                                    "3 spot lights + ambient, reps 16, aperture 0.05, depth 16",
                        "width": W, "height": H, "spp": spec.AntiAliasingFactor, "shapes": info["n_shapes"],
-                       "octree_blocks": info["n_inner_nodes"], "child_records": info["n_child_records"],
+                       "tree_blocks": info["n_inner_nodes"], "child_records": info["n_child_records"],
                        "tree_depth": info["tree_depth"], "partition": "samples" if world > 1 else "all",
                        "real_stl": bool(os.environ.get("RTGO_DRAGON_STL"))},
             "rays_per_frame": {"primary": n_prim / args.steps, "continuation": n_cont / args.steps,

@@ -1,6 +1,6 @@
 /*
  * rtgo.h — C-ABI of librtgo_hip.so, the MI355X (gfx950) render backend for the
- * raytracer-go hot path:  camera ray-gen -> octree traversal + ray/sphere +
+ * raytracer-go hot path:  camera ray-gen -> BVH traversal + ray/sphere +
  * ray/triangle -> material shading -> Monte-Carlo shadow rays -> pixel
  * accumulate -> RGBA8.
  *
@@ -125,7 +125,7 @@ typedef struct rt_stats {
                                     before its spot-cone test, light.go:124            */
     uint64_t phong_hits;
     uint64_t paths;              /* (pixel, sample) pairs rendered by this call        */
-    double ms_build;             /* host octree build + flatten + upload (scene create)*/
+    double ms_build;             /* host tree build + flatten + upload (scene create)  */
     double ms_render;            /* device time of the render call (hipEvent)          */
     double ms_extend, ms_shadow, ms_shade; /* per-stage device time, if timed          */
 } rt_stats;
@@ -137,7 +137,7 @@ typedef struct rt_scene_info {
     int64_t device_bytes;
 } rt_scene_info;
 
-typedef struct rt_scene rt_scene; /* opaque: flattened octree + tables resident in HBM */
+typedef struct rt_scene rt_scene; /* opaque: flattened tree + tables resident in HBM */
 
 /* Thread-local text of the last error.  The Go shim turns it into a panic, matching
  * the reference's error behaviour (accelerationstructures.go:73, example.go:36-44). */
@@ -148,8 +148,10 @@ int rt_init(int device);
 
 /* Replaces NewBoundingVolumeHierarchy(&scene.Shapes) (accelerationstructures.go:27-65,
  * called at raytracer.go:69) + NewCamera (camera.go:18-35, raytracer.go:59-68):
- * builds the octree on the host, flattens it to child-record / primitive arrays and
- * uploads scene, materials, textures and lights to `device`. */
+ * builds the acceleration structure on the host, flattens it to child-record / primitive arrays and
+ * uploads scene, materials, textures and lights to `device`.  The structure is a binned-SAH 8-wide BVH
+ * by default and the reference's insertion octree with RTGO_TREE=octree: both enclose every shape, so
+ * both return the reference's hits (INTEGRATION.md lists the switches).  Coordinates must be finite. */
 int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 int rt_scene_get_info(const rt_scene* scene, rt_scene_info* out);

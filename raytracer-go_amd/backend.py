@@ -70,7 +70,7 @@ def init(device=0):
 
 
 class DeviceScene:
-    """A Scene resident in HBM: flattened octree + shape / material / texture / light tables."""
+    """A Scene resident in HBM: flattened tree + shape / material / texture / light tables."""
 
     def __init__(self, scene, device=0):
         self._h = C.c_void_p()
