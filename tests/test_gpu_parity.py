@@ -294,6 +294,30 @@ def test_edge_cases(backend, bridge, rt):
             assert tuple(dev.render(s)[0][12, 20, :3]) == (0, 127, 0)
 
 
+def test_spot_cone_pair_culling_is_exact(backend, bridge, rt):
+    """Pairs that lie outside a spot cone for every jittered light position are not even queued on the
+    device; the oracle tests the cone per ray.  Equal traced-ray counts and equal radiance over lights
+    that are very close to the surface (inside the jitter radius), narrow, wide and nearly
+    omnidirectional show that no pair with a ray inside the cone is dropped."""
+    V = rt.Vec
+    mat = rt.PhongBlinn(ColorFrac=V(0.8, 0.8, 0.8), SpecularColorFrac=V(0.5, 0.5, 0.5), SpecHardness=8)
+    shapes = [rt.TrianglePlane(V(-30, 0, -30), V(-30, 0, 30), V(30, 0, -30), False, mat),
+              rt.TrianglePlane(V(30, 0, 30), V(30, 0, -30), V(-30, 0, 30), False, mat),
+              rt.Sphere(V(0, 1.0, 2.0), 1.0, mat)]
+    for height, angle, look in ((0.1, 60.0, V(0.5, 0, 0)), (0.3, 5.0, V(0, 0, 1)), (2.0, 30.0, V(1, 0, 1)),
+                                (6.0, 120.0, V(0, 0, 0)), (3.0, 179.0, V(0, 6, 0)), (4.0, 1.0, V(0, 0, 2))):
+        scene = rt.Scene(CameraLookFrom=V(0, 5, -9), CameraLookAt=V(0, 0.5, 0), CameraUp=V(0, 1, 0), CameraFov=55.0, Shapes=shapes,
+                         Lights=[rt.SpotLight(ColorFrac=V(1, 0.9, 0.8), Position=V(0.3, height, -0.5), LightIntensity=20,
+                                              SpecularLightIntensity=5, LookAt=look, Angle=angle, InverseSquareLawDecayFactor=0.5)])
+        spec = rt.ImageSpec(96, 54, 2, 3, 8, 1, 0)
+        with backend.DeviceScene(scene) as dev, bridge.OracleScene(scene) as osc:
+            acc, st = dev.render_accum(spec)
+            ref, _, ctr = osc.render(spec, mode=bridge.F32_STACK, rgba=False)
+        assert st.rays_shadow == ctr["rays_shadow"], (height, angle, st.rays_shadow, ctr["rays_shadow"])
+        assert st.phong_hits == ctr["phong_hits"]
+        assert np.abs(acc.astype(np.float64) - ref).max() < 1e-4, (height, angle)
+
+
 def test_soft_shadow_repetition_counts(backend, bridge, rt):
     """Repetition counts that are not powers of two and > 64 exercise the lane-group ballot count."""
     V = rt.Vec
