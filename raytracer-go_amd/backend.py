@@ -28,7 +28,8 @@ def build(force=False):
     """Compile librtgo_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(_CSRC, f) for f in ("rtgo_hip.hip", "device_math.hpp", "octree.cpp", "octree.hpp")]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "rtgo.h"))
-    stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    libs = [LIB_PATH, os.path.join(_CSRC, "librtgo_spill.so")]  # the second is a test build (tiny LDS stack)
+    stale = any(not os.path.exists(l) or any(os.path.getmtime(s) > os.path.getmtime(l) for s in srcs) for l in libs)
     if force or stale:
         subprocess.check_call(["make", "-C", _CSRC, "-s"])
     return LIB_PATH

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <deque>
+#include <unordered_map>
 
 namespace rtgo {
 namespace {
@@ -424,6 +425,9 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
 
     struct Pending { int32_t node; int64_t patch; int32_t level; };  // patch = record whose w0 names this block
     std::deque<Pending> queue;
+    struct Block { int64_t first; int count; };
+    std::vector<Block> blocks;
+    std::unordered_map<int64_t, int64_t> block_of_first;
     const int32_t root = skip_chain(nodes, 0);
     if (nodes[root].n_shapes <= leaf_size) {
         // everything fits one leaf: synthetic root block with that leaf in octant 0
@@ -464,11 +468,32 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
             return false;
         }
         const uint32_t ref = ((uint32_t)first << 8) | present;
+        block_of_first[first] = (int64_t)blocks.size();
+        blocks.push_back({first, (int)(out->records.size() - (size_t)first)});
         if (p.patch < 0) out->root_ref = ref; else out->records[(size_t)p.patch].w0 = ref;
         out->n_inner++;
         if (p.level > out->depth) out->depth = p.level;
     }
-    out->stack_bound = 7 * out->depth + 1;
+    // Worst-case traversal stack: entering a block pushes at most (inner children - 1) entries and descends
+    // into one inner child, so the deepest stack below block b is need(b) = (inner(b) - 1) + max over its
+    // inner children of need(child).  Blocks are in breadth-first order: children come after their parent.
+    {
+        std::vector<int32_t> need(blocks.size(), 0);
+        for (int64_t i = (int64_t)blocks.size() - 1; i >= 0; --i) {
+            const int64_t first = blocks[(size_t)i].first;
+            const int n = blocks[(size_t)i].count;
+            int inner = 0, deepest = 0;
+            for (int k = 0; k < n; ++k) {
+                const ChildRecord& r = out->records[(size_t)(first + k)];
+                if (r.w1 & kLeafFlag) continue;
+                ++inner;
+                const auto it = block_of_first.find((int64_t)(r.w0 >> 8));
+                if (it != block_of_first.end()) deepest = std::max(deepest, need[(size_t)it->second]);
+            }
+            need[(size_t)i] = (inner > 0 ? inner - 1 : 0) + deepest;
+        }
+        out->stack_bound = (need.empty() ? 0 : need[0]) + 1;
+    }
     return true;
 }
 

@@ -50,7 +50,7 @@ struct FlatTree {
     uint32_t root_ref = 0;  // (first << 8) | present of the root block
     int64_t n_inner = 0;    // blocks
     int32_t depth = 0;      // levels of blocks below the root (root block = 1)
-    int32_t stack_bound = 1;
+    int32_t stack_bound = 1;  // exact worst case of the traversal stack for this tree
 };
 
 // shapes: desc->shapes[0..n). Returns nodes[0] = root.

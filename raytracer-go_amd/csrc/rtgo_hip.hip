@@ -31,7 +31,10 @@ using namespace rtgo;
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kMaxGridBlocks = 2048;  // 256 CUs x 8: persistent grid-stride kernels
+#ifndef RTGO_MAX_GRID
+#define RTGO_MAX_GRID 16384
+#endif
+constexpr int kMaxGridBlocks = RTGO_MAX_GRID;  // grid-stride kernels; k_shadow ms per frame at config 3: 1024 -> 708, 2048 -> 688, 4096 -> 666, 8192 -> 651, 16384 -> 634, 65536 -> 636
 constexpr int64_t kDefaultMaxPaths = (int64_t)1 << 23;
 constexpr int kDefaultLeafSizeSah = 6;  // measured on config 3 (k_shadow ms per frame): 2 -> 833, 3 -> 816, 4 -> 823, 6 -> 791, 8 -> 809
 constexpr int kDefaultLeafSize = 4;  // measured on config 3: 1 -> 2.84 s, 2 -> 2.58 s, 4 -> 2.42 s, 8 -> 2.48 s, 16 -> 2.76 s per frame
@@ -357,6 +360,7 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
     const unsigned long long gmask = group == 64 ? ~0ull : (((1ull << group) - 1ull) << gbase);
     unsigned long long launched = 0;
     for (unsigned long long it = 0; it < rounds; ++it) {
+        // interleaved, not a contiguous range per block: ranges differ too much in cost (1024 blocks: 1760 vs 708 ms)
         const unsigned long long idx = it * gstride + gtid;
         const bool active = idx < total;
         // the pair queue is light-major: the lane groups of a wavefront are consecutive hits (neighbouring

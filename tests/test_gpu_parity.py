@@ -349,7 +349,7 @@ def test_soft_shadow_repetition_counts(backend, bridge, rt):
 
 
 @pytest.mark.parametrize("tree", ["octree", "sah"])
-def test_deep_tree_uses_stack_spill(backend, bridge, rt, tree, monkeypatch):
+def test_deep_reference_tree(backend, bridge, rt, tree, monkeypatch):
     """Nearly coincident centroids make the octree recurse until the 1e-10 jitter separates them
     (accelerationstructures.go:265-279); single-child chains are dropped by the flattener and the
     traversal stack may exceed its LDS part.  Results still match the oracle bit for bit."""
@@ -375,6 +375,43 @@ def test_deep_tree_uses_stack_spill(backend, bridge, rt, tree, monkeypatch):
         assert np.array_equal(gp, op) and np.array_equal(gt[gp >= 0], ot[gp >= 0].astype(np.float32))
         p64, _ = osc.trace_rays(rays.astype(np.float64), mode=bridge.F64_DIJKSTRA)
         assert (gp != p64).mean() < 5e-3
+
+
+def test_stack_spill_path(backend, bridge, rt, scenes):
+    """librtgo_spill.so is the same source built with 2 traversal-stack entries in LDS instead of 20, so
+    nearly every push and pop goes through the global spill region that real scenes touch only on their
+    deepest rays.  Nearest hits, shadow rays and a small frame must not change."""
+    import os
+
+    spill_lib = os.path.join(os.path.dirname(backend.LIB_PATH), "librtgo_spill.so")
+    assert os.path.exists(spill_lib), "built by __graft_entry__.build()"
+    spec, scene = _mesh_scene(rt, scenes)
+    px = _rand_pixels(spec, 20000, 12)
+    with backend.DeviceScene(scene) as dev:
+        rays = np.zeros((px.shape[0], 8), np.float32)
+        rays[:, :6] = dev.camera_rays(spec, px)
+        want_p, want_t = dev.trace_rays(rays)
+        hit = want_p >= 0
+        sh = np.zeros((int(hit.sum()), 8), np.float32)
+        o = rays[hit, :3] + want_t[hit, None] * rays[hit, 3:6]
+        v = np.array([4, 8, -5], np.float32) - o
+        dist = np.sqrt((v * v).sum(1)).astype(np.float32)
+        sh[:, :3], sh[:, 3:6], sh[:, 6], sh[:, 7] = o, v / dist[:, None], 0.01, dist
+        want_occ, _ = dev.trace_rays(sh, any_hit=True)
+        want_acc, want_st = dev.render_accum(spec)
+    saved = (backend.LIB_PATH, backend._lib)
+    try:
+        backend.LIB_PATH, backend._lib = spill_lib, None
+        with backend.DeviceScene(scene) as dev:
+            assert dev.info()["stack_bound"] > 2
+            got_p, got_t = dev.trace_rays(rays)
+            got_occ, _ = dev.trace_rays(sh, any_hit=True)
+            got_acc, got_st = dev.render_accum(spec)
+    finally:
+        backend.LIB_PATH, backend._lib = saved
+    assert np.array_equal(got_p, want_p) and np.array_equal(got_t[hit], want_t[hit])
+    assert np.array_equal(got_occ, want_occ) and 0 < want_occ.mean() < 1
+    assert np.array_equal(got_acc, want_acc) and got_st.rays_shadow == want_st.rays_shadow
 
 
 def test_large_mesh_properties(backend, bridge, rt, scenes):
