@@ -5,11 +5,12 @@
 //   extend     accelerationstructures.go:81-124          1 lane / live ray, ordered stack traversal
 //   shade      raytracer.go:143-161 + material.go:34-70  1 lane / hit; Metal/Dielectric continue,
 //                                                         PhongBlinn hits go to the phong queue
-//   shadow     material.go:76-82 + light.go:93-160       1 lane / (hit, light, repetition); any-hit
+//   pairs      material.go:83-119 (visibility-free part) 1 lane / PhongBlinn hit: which (hit, light) pairs need rays
+//   shadow     material.go:76-82 + light.go:93-160       1 lane / (queued pair, repetition); any-hit
 //   phong      material.go:83-131                         1 lane / PhongBlinn hit
 //   accumulate raytracer.go:117-119                       1 lane / pixel (fixed-order sample sum)
 //   resolve    raytracer.go:93-96,125                     1 lane / pixel -> RGBA8
-// Queues are compacted with a 64-lane ballot + popcount prefix and one atomic per wavefront.
+// Queues are compacted with a 64-lane ballot + popcount prefix and one atomic per 256-thread block.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
