@@ -60,8 +60,17 @@ def lib():
                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_scatter_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_void_p]
+        L.orc_sample_unit_sphere.argtypes = [C.c_uint64, C.c_int64, C.c_void_p]
+        L.orc_sample_unit_sphere.restype = None
         _lib = L
     return _lib
+
+
+def sample_unit_sphere(n, seed=0x5EED):
+    """n draws of the oracle's randomInUnitSphere restatement (float64), for distribution tests."""
+    out = np.empty((n, 3), dtype=np.float64)
+    lib().orc_sample_unit_sphere(seed, n, out.ctypes.data)
+    return out
 
 
 def default_threads():

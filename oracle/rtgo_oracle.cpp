@@ -1440,4 +1440,13 @@ int orc_scatter_probe(const orc_scene* s, const rt_image_spec* spec, uint64_t se
     return 0;
 }
 
+// n samples of random_in_unit_sphere (float64 form) for the distribution test: out = n * 3 doubles
+void orc_sample_unit_sphere(uint64_t seed, int64_t n, double* out) {
+    for (int64_t i = 0; i < n; ++i) {
+        const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(i & 0xffffffff), (uint32_t)(i >> 32)};
+        const V3<double> p = random_in_unit_sphere<double>(key, 3, P_SHADOW, (uint32_t)(i % 48));
+        out[3 * i] = p.x; out[3 * i + 1] = p.y; out[3 * i + 2] = p.z;
+    }
+}
+
 }  // extern "C"

@@ -152,3 +152,23 @@ def test_oracle_reproduces_committed_vectors(bridge, c1, gold_dir):
             assert row[0] == 1.0 and np.allclose(row[4:7], row[14:17] + 1e-5 * row[7:10], atol=1e-15)
         else:                        # Standard, PhongBlinn: terminal colour
             assert row[0] == 0.0 and (row[10:13] >= 0).all() and (row[10:13] <= 1.0001).all()
+
+
+def test_unit_sphere_sampler_is_uniform_in_the_ball(bridge):
+    """randomInUnitSphere (material.go:134-143): cube rejection fed by one Philox block + xorshift128 retries.
+    Device and oracle share that stream definition, so its distribution is pinned here on its own: moments
+    and cell probabilities of the uniform unit ball."""
+    n = 1_000_000
+    p = bridge.sample_unit_sphere(n)
+    r2 = (p * p).sum(1)
+    assert r2.max() < 1.0
+    tol = 5.0 / np.sqrt(n)  # ~5 sigma for O(1)-variance statistics
+    assert np.abs(p.mean(0)).max() < tol
+    assert abs(r2.mean() - 0.6) < tol and np.abs((p * p).mean(0) - 0.2).max() < tol
+    assert np.abs(np.cov(p.T) - np.eye(3) * 0.2).max() < tol
+    for radius in (0.25, 0.5, 0.75, 0.9):
+        assert abs((r2 < radius * radius).mean() - radius ** 3) < tol
+    octant = (p[:, 0] > 0) * 1 + (p[:, 1] > 0) * 2 + (p[:, 2] > 0) * 4
+    assert np.abs(np.bincount(octant, minlength=8) / n - 0.125).max() < tol
+    z = p[:, 2] / np.sqrt(r2)  # direction: cos(theta) uniform on [-1, 1]
+    assert np.abs(np.histogram(z, bins=10, range=(-1, 1))[0] / n - 0.1).max() < tol
