@@ -87,6 +87,7 @@ constexpr uint32_t kPrimSingleSided = 2u;
 struct DScene {
     const float4* recs;    // 2 float4 per child record: {min.xyz, max.x}, {max.y, max.z, w0, w1}
     const float4* prims;   // 3 float4 per shape, in LEAF order: tri {A, B.x}{B.yz, C.xy}{C.z, bits, -, -}; sphere {C, R}{-}{-, bits}
+    const float4* tprims;  // the same for the intersection tests: edges e1 = B - A, e2 = C - A in place of B, C
     const int* prim_ids;   // leaf-order shape q -> position in Scene.Shapes
     const DMaterial* materials;
     const DTexture* textures;
@@ -109,8 +110,8 @@ RT_DEV float sphere_hit(const float4 p0, f3 o, f3 d, float tmin, float tmax) {
     }
     return -1.0f;
 }
-RT_DEV float triangle_hit(f3 A, f3 B, f3 C, bool single_sided, f3 o, f3 d, float tmin, float tmax) {
-    const f3 e1 = sub3(B, A), e2 = sub3(C, A);
+// e1 = B - A, e2 = C - A come precomputed (DScene::tprims): the same fp32 values shape.go:119-120 would give
+RT_DEV float triangle_hit(f3 A, f3 e1, f3 e2, bool single_sided, f3 o, f3 d, float tmin, float tmax) {
     const f3 pvec = cross3(d, e2);
     const float det = dot3(e1, pvec);
     if (single_sided && det < 0.0f) return -1.0f;
@@ -134,8 +135,7 @@ RT_DEV float dotf(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z))
 RT_DEV f3 crossf(f3 a, f3 b) {
     return mk3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
-RT_DEV float triangle_occludes(f3 A, f3 B, f3 C, bool single_sided, f3 o, f3 d, float tmin, float tmax) {
-    const f3 e1 = sub3(B, A), e2 = sub3(C, A);
+RT_DEV float triangle_occludes(f3 A, f3 e1, f3 e2, bool single_sided, f3 o, f3 d, float tmin, float tmax) {
     const f3 pvec = crossf(d, e2);
     const float det = dotf(e1, pvec);
     const f3 tvec = sub3(o, A);
@@ -152,9 +152,9 @@ RT_DEV float triangle_occludes(f3 A, f3 B, f3 C, bool single_sided, f3 o, f3 d, 
 template <bool ANY>
 RT_DEV float prim_hit(const DScene& S, uint32_t prim, f3 o, f3 d, float tmin, float tmax) {
     // all three quads are fetched together (a sphere ignores p1): one memory latency per shape
-    float4 p0 = S.prims[3 * (size_t)prim];
-    float4 p1 = S.prims[3 * (size_t)prim + 1];
-    float4 p2 = S.prims[3 * (size_t)prim + 2];
+    float4 p0 = S.tprims[3 * (size_t)prim];
+    float4 p1 = S.tprims[3 * (size_t)prim + 1];
+    float4 p2 = S.tprims[3 * (size_t)prim + 2];
     // keeps the compiler from sinking the p1 / p2 loads below the triangle-or-sphere branch, which would
     // make them a second, dependent memory round trip per shape
     asm volatile("" : "+v"(p0.x), "+v"(p1.x), "+v"(p2.x), "+v"(p2.y));

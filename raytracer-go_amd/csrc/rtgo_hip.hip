@@ -508,7 +508,7 @@ __global__ __launch_bounds__(kBlock) void k_camera_probe(DCamera cam, int W, int
 struct rt_scene {
     int device = 0;
     DScene d{};
-    void* d_recs = nullptr; void* d_prims = nullptr; void* d_prim_ids = nullptr; void* d_mats = nullptr; void* d_texs = nullptr; void* d_lights = nullptr;
+    void* d_recs = nullptr; void* d_prims = nullptr; void* d_tprims = nullptr; void* d_prim_ids = nullptr; void* d_mats = nullptr; void* d_texs = nullptr; void* d_lights = nullptr;
     std::vector<void*> d_tex_pixels;
     rt_scene_info info{};
     double ms_build = 0;
@@ -691,6 +691,18 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         }
         std::memcpy(&p[9], &bits, 4);
     }
+    // the same records for the intersection tests, with the triangle's edges e1 = B - A, e2 = C - A (fp32
+    // differences of the fp32 vertices, exactly what the tests would compute) in place of B and C
+    std::vector<float> tprims(prims);
+    for (int64_t q = 0; q < desc->n_shapes; ++q) {
+        float* p = tprims.data() + (size_t)q * 12;
+        uint32_t bits;
+        std::memcpy(&bits, &p[9], 4);
+        if (!(bits & kPrimTriangle)) continue;
+        const float ax = p[0], ay = p[1], az = p[2];
+        p[6] = p[6] - ax; p[7] = p[7] - ay; p[8] = p[8] - az;
+        p[3] = p[3] - ax; p[4] = p[4] - ay; p[5] = p[5] - az;
+    }
     std::vector<DMaterial> mats((size_t)desc->n_materials + 1);
     for (int64_t i = 0; i < desc->n_materials; ++i) {
         const rt_material& m = desc->materials[i];
@@ -757,6 +769,8 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     if (!flat.records.empty()) HIP_TRY_S(hipMemcpy(s->d_recs, flat.records.data(), flat.records.size() * sizeof(ChildRecord), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_prims, prims.size() * sizeof(float)));
     HIP_TRY_S(hipMemcpy(s->d_prims, prims.data(), prims.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_tprims, tprims.size() * sizeof(float)));
+    HIP_TRY_S(hipMemcpy(s->d_tprims, tprims.data(), tprims.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_prim_ids, (flat.order.size() + 1) * sizeof(int32_t)));
     if (!flat.order.empty()) HIP_TRY_S(hipMemcpy(s->d_prim_ids, flat.order.data(), flat.order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_mats, mats.size() * sizeof(DMaterial)));
@@ -771,7 +785,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     s->wk.overflow_stride = (uint32_t)kMaxGridBlocks * kBlock;
     HIP_TRY_S(hipMalloc((void**)&s->wk.overflow, (size_t)(spill + 1) * s->wk.overflow_stride * sizeof(uint32_t)));
 
-    s->d.recs = (const float4*)s->d_recs; s->d.prims = (const float4*)s->d_prims; s->d.prim_ids = (const int*)s->d_prim_ids;
+    s->d.recs = (const float4*)s->d_recs; s->d.prims = (const float4*)s->d_prims; s->d.tprims = (const float4*)s->d_tprims; s->d.prim_ids = (const int*)s->d_prim_ids;
     s->d.materials = (const DMaterial*)s->d_mats; s->d.textures = (const DTexture*)s->d_texs;
     s->d.lights = (const DLight*)s->d_lights;
     s->d.n_lights = (int)desc->n_lights; s->d.n_pos_lights = n_pos; s->d.root_ref = flat.root_ref;
@@ -781,7 +795,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     s->info.n_shapes = desc->n_shapes; s->info.n_inner_nodes = flat.n_inner;
     s->info.n_child_records = (int64_t)flat.records.size();
     s->info.tree_depth = flat.depth; s->info.stack_bound = flat.stack_bound;
-    s->info.device_bytes = (int64_t)(rec_bytes + prims.size() * 4 + mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
+    s->info.device_bytes = (int64_t)(rec_bytes + prims.size() * 4 + tprims.size() * 4 + mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
                                      lights.size() * sizeof(DLight) + (size_t)(spill + 1) * s->wk.overflow_stride * 4) + tex_bytes;
     s->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out = s;
@@ -795,7 +809,7 @@ void rt_scene_destroy(rt_scene* s) {
     free_work(s);
     if (s->wk.overflow) (void)hipFree(s->wk.overflow);
     if (s->h_counters) (void)hipHostFree(s->h_counters);
-    void* ptrs[] = {s->d_recs, s->d_prims, s->d_prim_ids, s->d_mats, s->d_texs, s->d_lights};
+    void* ptrs[] = {s->d_recs, s->d_prims, s->d_tprims, s->d_prim_ids, s->d_mats, s->d_texs, s->d_lights};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : s->d_tex_pixels) (void)hipFree(p);
     if (s->ev_ok) for (auto& e : s->ev) (void)hipEventDestroy(e);
