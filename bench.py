@@ -142,7 +142,7 @@ def main():
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj["workload"] == {"width": W, "height": H, "spp": spec.AntiAliasingFactor, "config": "config3"}:
+            if world == 1 and tj["workload"] == {"width": W, "height": H, "spp": spec.AntiAliasingFactor, "config": "config3"}:  # per-launch figures of the 1-GPU run
                 traffic = tj["hbm_bytes_per_launch"]
                 isu = tj.get("issue")
                 if isu and shadow_s > 0 and world == 1:
