@@ -15,6 +15,8 @@
  *     library narrows to fp32 at upload (the device path computes in fp32).
  *   - All input pointers are borrowed for the duration of the call only.
  *   - Return 0 = RT_OK; negative = error, text via rt_last_error() (thread-local).
+ *   - An rt_scene owns its device workspace: one call at a time per scene (different scenes,
+ *     e.g. one per device, may be used from different threads concurrently).
  *   - Shape index (position in rt_scene_desc.shapes) is the primitive ID that
  *     rt_trace_rays reports — same order as Scene.Shapes (raytracer.go:44).
  */

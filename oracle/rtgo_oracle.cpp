@@ -442,7 +442,8 @@ struct SahTree {
         const int k = (int)((c - lo) * scale);
         return k >= kBins ? kBins - 1 : k;
     }
-    int split(int b, int e) {
+    static constexpr int kMaxSahDepth = 48;  // deeper levels halve the range (device builder rule)
+    int split(int b, int e, int depth = 0) {
         const V3<double> big{DBL_MAX, DBL_MAX, DBL_MAX}, small{-DBL_MAX, -DBL_MAX, -DBL_MAX};
         SahSplit nd;
         nd.b = b; nd.e = e; nd.lo = big; nd.hi = small;
@@ -453,7 +454,7 @@ struct SahTree {
         if (e - b <= leaf_size) return me;
         int best_axis = -1, best_k = 0;
         double best_cost = DBL_MAX;
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < 3 && depth < kMaxSahDepth; ++a) {
             const double ext = axis_of(chi, a) - axis_of(clo, a);
             if (!(ext > 0)) continue;
             const double scale = kBins / ext;
@@ -493,8 +494,8 @@ struct SahTree {
             std::copy(left.begin(), left.end(), shp.begin() + b);
             std::copy(right.begin(), right.end(), shp.begin() + mid);
         }
-        const int l = split(b, mid);
-        const int r = split(mid, e);
+        const int l = split(b, mid, depth + 1);
+        const int r = split(mid, e, depth + 1);
         nodes[(size_t)me].left = l; nodes[(size_t)me].right = r;
         return me;
     }

@@ -178,11 +178,14 @@ double area3(const double lo[3], const double hi[3]) {
     const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
     return 2.0 * ((dx * dy + dy * dz) + dz * dx);
 }
+constexpr int kMaxSahDepth = 48;
 struct SahBuilder {
     std::vector<SahItem> items;
     std::vector<Bvh2> b2;
     int leaf_size;
-    int32_t build(int32_t b, int32_t e) {
+    // depth: SAH may split 1 : n-1 again and again on adversarial input; beyond kMaxSahDepth levels the
+    // range is halved instead, so the recursion stays O(kMaxSahDepth + log n) deep
+    int32_t build(int32_t b, int32_t e, int depth = 0) {
         Bvh2 nd;
         nd.b = b; nd.e = e;
         double clo[3], chi[3];
@@ -198,7 +201,7 @@ struct SahBuilder {
         constexpr int kBins = 16;
         int best_axis = -1, best_split = 0;
         double best_cost = DBL_MAX;
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < 3 && depth < kMaxSahDepth; ++a) {
             const double ext = chi[a] - clo[a];
             if (!(ext > 0)) continue;
             struct Bin { double lo[3], hi[3]; int n; } bins[kBins];
@@ -243,8 +246,8 @@ struct SahBuilder {
             mid = (int32_t)(it - items.begin());
             if (mid == b || mid == e) mid = b + (e - b) / 2;
         }
-        const int32_t l = build(b, mid);
-        const int32_t r = build(mid, e);
+        const int32_t l = build(b, mid, depth + 1);
+        const int32_t r = build(mid, e, depth + 1);
         b2[me].left = l; b2[me].right = r;
         return me;
     }

@@ -61,7 +61,7 @@ std::vector<HostNode> build_octree(const rt_shape* shapes, int64_t n);
 //     (<= 8) shapes -> leaf.  Otherwise, per axis with a positive centroid extent, 16 equal bins;
 //     for every bin boundary with shapes on both sides cost = area(left) * n_left + area(right) *
 //     n_right; strictly smallest cost wins (first axis / boundary on ties); the range is split stably;
-//     with no valid boundary, in the middle.
+//     with no valid boundary, or more than 48 levels down, in the middle.
 //   widen(node): children = {left, right}; while fewer than 8 and some child is inner, the inner child
 //     with the largest area (first on ties) is replaced by its left child, its right child appended;
 //     children take slots by the greedy octant matching of block_slots.  A leaf's shapes become

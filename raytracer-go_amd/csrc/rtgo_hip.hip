@@ -516,6 +516,7 @@ struct rt_scene {
     rt_vec3 from, at, up; double aperture = 0, fov = 0;
     // batch workspace, grown on demand
     Work wk{}; int64_t wk_paths = 0; int wk_depth = 0; int wk_lpos = 0;
+    int spill = 0;  // traversal-stack entries beyond the LDS part (from the tree's exact worst case)
     uint32_t* h_counters = nullptr;  // pinned
     hipEvent_t ev[8] = {};
     bool ev_ok = false;
@@ -595,6 +596,19 @@ int validate_spec(const rt_image_spec* spec) {
         return fail(RT_ERR_INVALID, "negative AntiAliasingFactor / RayTracingMaxDepth / SoftShadowMonteCarloRepetitions");
     if (spec->ray_tracing_max_depth > (1 << 20)) return fail(RT_ERR_LIMIT, "RayTracingMaxDepth > 2^20");
     if (spec->soft_shadow_monte_carlo_repetitions > (1 << 16)) return fail(RT_ERR_LIMIT, "SoftShadowMonteCarloRepetitions > 65536");
+    return RT_OK;
+}
+
+// The spill region holds (spill + 1) entries for every thread of the largest grid launched so far.
+int ensure_overflow(rt_scene* s, unsigned long long lanes) {
+    unsigned long long blocks = (lanes + kBlock - 1) / kBlock;
+    if (blocks < 256) blocks = 256;
+    if (blocks > (unsigned long long)kMaxGridBlocks) blocks = (unsigned long long)kMaxGridBlocks;
+    const uint32_t stride = (uint32_t)blocks * kBlock;
+    if (s->wk.overflow && s->wk.overflow_stride >= stride) return RT_OK;
+    if (s->wk.overflow) { (void)hipFree(s->wk.overflow); s->wk.overflow = nullptr; s->wk.overflow_stride = 0; }
+    HIP_TRY(hipMalloc((void**)&s->wk.overflow, (size_t)(s->spill + 1) * stride * sizeof(uint32_t)));
+    s->wk.overflow_stride = stride;
     return RT_OK;
 }
 
@@ -782,8 +796,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
 
     // traversal stack spill: worst case 7 pending siblings per level, beyond the LDS part
     const int spill = flat.stack_bound > kLdsStackDepth ? flat.stack_bound - kLdsStackDepth : 0;
-    s->wk.overflow_stride = (uint32_t)kMaxGridBlocks * kBlock;
-    HIP_TRY_S(hipMalloc((void**)&s->wk.overflow, (size_t)(spill + 1) * s->wk.overflow_stride * sizeof(uint32_t)));
+    s->spill = spill;  // the region itself is sized by ensure_overflow() for the grids a call really launches
 
     s->d.recs = (const float4*)s->d_recs; s->d.prims = (const float4*)s->d_prims; s->d.tprims = (const float4*)s->d_tprims; s->d.prim_ids = (const int*)s->d_prim_ids;
     s->d.materials = (const DMaterial*)s->d_mats; s->d.textures = (const DTexture*)s->d_texs;
@@ -796,7 +809,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     s->info.n_child_records = (int64_t)flat.records.size();
     s->info.tree_depth = flat.depth; s->info.stack_bound = flat.stack_bound;
     s->info.device_bytes = (int64_t)(rec_bytes + prims.size() * 4 + tprims.size() * 4 + mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
-                                     lights.size() * sizeof(DLight) + (size_t)(spill + 1) * s->wk.overflow_stride * 4) + tex_bytes;
+                                     lights.size() * sizeof(DLight)) + tex_bytes;  // + the spill region, see ensure_overflow()
     s->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out = s;
     return RT_OK;
@@ -862,7 +875,11 @@ int rt_render_accum_device(rt_scene* s, const rt_image_spec* spec, const rt_part
         if (max_paths > pair_cap) max_paths = pair_cap;
         const int ns_max = (int)std::min<long long>(sB - sA, std::min<long long>(64, max_paths / ((long long)tile * tile)));
         const long long pix_per_batch = std::max<long long>(1, max_paths / ns_max / ((long long)tile * tile)) * tile * tile;
-        rc = ensure_work(s, (int64_t)std::min<long long>(pix_per_batch, n_local_pixels) * ns_max, D, s->d.n_pos_lights);
+        const int64_t batch_paths = (int64_t)std::min<long long>(pix_per_batch, n_local_pixels) * ns_max;
+        rc = ensure_work(s, batch_paths, D, s->d.n_pos_lights);
+        if (rc != RT_OK) return rc;
+        // the widest launch is k_shadow's: one lane per (pair, repetition lane), at most 64 lanes per pair
+        rc = ensure_overflow(s, (unsigned long long)batch_paths * (unsigned long long)std::max(1, s->d.n_pos_lights) * 64ull);
         if (rc != RT_OK) return rc;
         Work& wk = s->wk;
         // lanes per (hit, light) in the shadow kernel: smallest power of two >= min(reps, 64)
@@ -1034,6 +1051,8 @@ int rt_trace_rays(rt_scene* s, const float* rays, int64_t n, int32_t any_hit, in
     if (n > ((int64_t)1 << 30)) return fail(RT_ERR_LIMIT, "more than 2^30 rays in one call");
     HIP_TRY(hipSetDevice(s->device));
     float* d_rays = nullptr; int* d_prim = nullptr; float* d_t = nullptr;
+    int rc = ensure_overflow(s, (unsigned long long)n);
+    if (rc != RT_OK) return rc;
     HIP_TRY(hipMalloc((void**)&d_rays, (size_t)n * 8 * sizeof(float)));
     hipError_t e = hipMalloc((void**)&d_prim, (size_t)n * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&d_t, (size_t)n * sizeof(float));

@@ -377,6 +377,31 @@ def test_deep_reference_tree(backend, bridge, rt, tree, monkeypatch):
         assert (gp != p64).mean() < 5e-3
 
 
+def test_exponentially_spaced_shapes(backend, bridge, rt):
+    """Shapes whose spacing grows geometrically make binned SAH peel off a few shapes per level (most
+    centroids fall into the first bin); the builders stop using SAH 48 levels down and halve ranges
+    instead.  Device and oracle must still build the same tree and find the same hits."""
+    V = rt.Vec
+    mat = rt.Standard(ColorFrac=V(1, 1, 1))
+    shapes = []
+    for i in range(1500):
+        x = 1.1 ** (i / 10.0)
+        shapes.append(rt.Sphere(V(x, 0.02 * x * ((i % 7) - 3), 0.03 * x * ((i % 5) - 2)), 0.04 * x, mat))
+    scene = rt.Scene(CameraLookFrom=V(-5, 1, -40), CameraLookAt=V(60, 0, 0), CameraUp=V(0, 1, 0), CameraFov=70.0, Shapes=shapes, Lights=[])
+    spec = rt.ImageSpec(128, 72, 1, 2, 1, 1, 0)
+    with backend.DeviceScene(scene) as dev, bridge.OracleScene(scene) as osc:
+        print("exponential scene:", dev.info())
+        px = _rand_pixels(spec, 9216, 3)
+        rays = np.zeros((px.shape[0], 8), np.float32)
+        rays[:, :6] = dev.camera_rays(spec, px)
+        gp, gt = dev.trace_rays(rays)
+        op, ot = osc.trace_rays(rays.astype(np.float64), mode=bridge.F32_STACK)
+        assert np.array_equal(gp, op) and np.array_equal(gt[gp >= 0], ot[gp >= 0].astype(np.float32))
+        assert (gp >= 0).mean() > 0.02
+        p64, _ = osc.trace_rays(rays.astype(np.float64), mode=bridge.F64_DIJKSTRA)
+        assert (gp != p64).mean() < 5e-3
+
+
 def test_stack_spill_path(backend, bridge, rt, scenes):
     """librtgo_spill.so is the same source built with 2 traversal-stack entries in LDS instead of 20, so
     nearly every push and pop goes through the global spill region that real scenes touch only on their
