@@ -318,6 +318,39 @@ def test_spot_cone_pair_culling_is_exact(backend, bridge, rt):
         assert np.abs(acc.astype(np.float64) - ref).max() < 1e-4, (height, angle)
 
 
+def test_textures_and_uv_maps_match_oracle(backend, bridge, rt, gold_dir):
+    """T1 / T2 / S3 on their own: unlit Standard materials show the texture colour directly, so the frame is
+    the UV maps (sphere atan2 / acos, triangle u = 1 - w quirk) and the texel / checker arithmetic
+    (floor-to-int parity, alpha over background, no clamp at u = 1).  Device vs the fp32 mirror and vs
+    the reference-faithful fp64 mode; the few pixels allowed to differ are texel or checker boundaries
+    where atan2f / acosf differ from glibc by an ulp."""
+    import os
+
+    V = rt.Vec
+    with open(os.path.join(gold_dir, "samples_textures", "Tiles075_1K_Color.jpg"), "rb") as f:
+        img = rt.ImageTexture(rt.LoadRGBAImage(f))
+    small = rt.ImageTexture(rt.RGBAImage(np.array([[[255, 0, 0, 255], [0, 255, 0, 128]], [[0, 0, 255, 0], [254, 254, 254, 255]]], np.uint8)))
+    chk = rt.CheckersTexture(V(0.9, 0.1, 0.1), V(0.1, 0.1, 0.9), 7.0, 3.0)
+    shapes = [rt.TrianglePlane(V(-6, 0, 6), V(-6, 0, -4), V(6, 0, 6), False, rt.Standard(Texture=img)),
+              rt.TrianglePlane(V(6, 0, -4), V(6, 0, 6), V(-6, 0, -4), True, rt.Standard(Texture=chk)),
+              rt.TrianglePlane(V(-6, 0, 6), V(6, 0, 6), V(-6, 6, 6), False, rt.Standard(Texture=small)),
+              rt.Sphere(V(-2.2, 1.2, 1.0), 1.2, rt.Standard(Texture=img)),
+              rt.Sphere(V(0.6, 1.0, 0.0), 1.0, rt.Standard(Texture=chk)),
+              rt.Sphere(V(2.8, 0.8, 1.5), 0.8, rt.Standard(Texture=small))]
+    scene = rt.Scene(CameraLookFrom=V(0, 3.5, -7), CameraLookAt=V(0, 1, 1), CameraUp=V(0, 1, 0), CameraFov=55.0, Shapes=shapes, Lights=[])
+    spec = rt.ImageSpec(256, 144, 2, 2, 1, 1, 0)
+    with backend.DeviceScene(scene) as dev, bridge.OracleScene(scene) as osc:
+        acc, st = dev.render_accum(spec)
+        ref32, _, ctr = osc.render(spec, mode=bridge.F32_STACK, rgba=False)
+        ref64, _, _ = osc.render(spec, mode=bridge.F64_DIJKSTRA, rgba=False)
+    assert st.rays_primary == ctr["rays_primary"] and st.rays_shadow == 0 and st.phong_hits == 0
+    d32 = np.abs(acc.astype(np.float64) - ref32).max(-1)
+    d64 = np.abs(acc.astype(np.float64) - ref64).max(-1)
+    print(f"texture frame: {(d32 > 1e-4).sum()} px differ from the fp32 mirror, {(d64 > 1e-4).sum()} from fp64, of {d32.size}")
+    assert (d32 > 1e-4).mean() < 2e-3 and (d64 > 1e-4).mean() < 1e-2
+    assert len(np.unique((acc * 255).round().astype(int).reshape(-1, 3), axis=0)) > 500  # the image texture is really sampled
+
+
 def test_soft_shadow_repetition_counts(backend, bridge, rt):
     """Repetition counts that are not powers of two and > 64 exercise the lane-group ballot count."""
     V = rt.Vec
