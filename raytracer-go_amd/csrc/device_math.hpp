@@ -236,14 +236,15 @@ RT_DEV void visit_block(const DScene& S, uint32_t cur, const TraceRay& r, float 
                         uint32_t* leaf_mask, uint32_t* inner_mask) {
     RT_PROF_POINT(0);  // block visits
     const uint32_t first = cur >> 8, present = cur & 0xffu;
-    // All child records are fetched before any is tested, with no branch around the loads (an absent
-    // child re-reads the block's first record): one memory latency per block instead of one per child.
+    // All child records are fetched before any is tested, with no branch around the loads: one memory
+    // latency per block instead of one per child.  A slot's record is first + (present slots below it);
+    // for an absent slot that is the record of the next present slot, or the record after the block's
+    // last (the array is padded by one), fetched and then masked out.
     float4 ra[8], rb[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const uint32_t oct = (uint32_t)k ^ r.sign;
-        const uint32_t below = (uint32_t)__popc(present & ((1u << oct) - 1u));
-        const size_t idx = (size_t)first + (((present >> oct) & 1u) ? below : 0u);
+        const size_t idx = (size_t)first + (uint32_t)__popc(present & ((1u << oct) - 1u));
         ra[k] = S.recs[2 * idx];
         rb[k] = S.recs[2 * idx + 1];
     }

@@ -780,6 +780,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
 
     const size_t rec_bytes = (flat.records.size() + 1) * sizeof(ChildRecord);
     HIP_TRY_S(hipMalloc(&s->d_recs, rec_bytes));
+    HIP_TRY_S(hipMemset(s->d_recs, 0, rec_bytes));  // the padding record is fetched (and masked out) for trailing absent slots
     if (!flat.records.empty()) HIP_TRY_S(hipMemcpy(s->d_recs, flat.records.data(), flat.records.size() * sizeof(ChildRecord), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_prims, prims.size() * sizeof(float)));
     HIP_TRY_S(hipMemcpy(s->d_prims, prims.data(), prims.size() * sizeof(float), hipMemcpyHostToDevice));
