@@ -1,0 +1,115 @@
+// CPU-only check of the host tree builders (raytracer-go_amd/csrc/octree.cpp), compiled by
+// tests/test_host_api.py with -fsanitize=address,undefined.  For random and degenerate scenes and both
+// builders it verifies the invariants the traversal relies on:
+//   - every shape is in exactly one leaf;
+//   - a leaf record's box encloses the bounds of the leaf's shapes, an inner record's box encloses
+//     every record of its block (so no ray can miss a shape by culling a box);
+//   - record / block indices are in range, blocks hold 1..8 records in slot order;
+//   - walking the blocks depth-first never needs more stack than FlatTree::stack_bound.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../../raytracer-go_amd/csrc/octree.hpp"
+
+using namespace rtgo;
+
+static int fails = 0;
+#define CHECK(cond, ...) do { if (!(cond)) { std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); ++fails; } } while (0)
+
+static void bounds(const rt_shape& s, double lo[3], double hi[3]) {
+    if (s.kind == RT_SHAPE_SPHERE) {
+        const double c[3] = {s.a.x, s.a.y, s.a.z};
+        for (int a = 0; a < 3; ++a) { lo[a] = c[a] - s.b.x; hi[a] = c[a] + s.b.x; }
+        return;
+    }
+    const double p[3][3] = {{s.a.x, s.a.y, s.a.z}, {s.b.x, s.b.y, s.b.z}, {s.c.x, s.c.y, s.c.z}};
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = std::fmin(p[0][a], std::fmin(p[1][a], p[2][a]));
+        hi[a] = std::fmax(p[0][a], std::fmax(p[1][a], p[2][a]));
+    }
+}
+
+static int max_stack = 0;
+static void walk(const FlatTree& t, uint32_t ref, int stack, const ChildRecord* parent, std::vector<int>& seen,
+                 const std::vector<rt_shape>& shapes, int depth) {
+    const uint32_t first = ref >> 8, present = ref & 0xffu;
+    const int n = __builtin_popcount(present);
+    CHECK(n >= 1 && n <= 8 && (size_t)first + n <= t.records.size(), "block %u has %d records", first, n);
+    CHECK(depth <= t.depth, "block deeper (%d) than FlatTree::depth %d", depth, t.depth);
+    int inner = 0;
+    for (int k = 0; k < n; ++k) inner += (t.records[first + k].w1 & kLeafFlag) ? 0 : 1;
+    const int here = stack + (inner > 0 ? inner - 1 : 0);
+    if (here > max_stack) max_stack = here;
+    for (int k = 0; k < n; ++k) {
+        const ChildRecord& r = t.records[first + k];
+        if (parent)
+            for (int a = 0; a < 3; ++a)
+                CHECK(r.bmin[a] >= parent->bmin[a] && r.bmax[a] <= parent->bmax[a], "record %u sticks out of its parent on axis %d", first + k, a);
+        if (r.w1 & kLeafFlag) {
+            const uint32_t pf = r.w0 >> 8, pc = r.w0 & 0xffu;
+            CHECK(pc >= 1 && (size_t)pf + pc <= t.order.size(), "leaf range %u+%u", pf, pc);
+            for (uint32_t q = pf; q < pf + pc && q < t.order.size(); ++q) {
+                const int sh = t.order[q];
+                CHECK(sh >= 0 && (size_t)sh < shapes.size(), "shape index %d", sh);
+                seen[(size_t)sh]++;
+                double lo[3], hi[3];
+                bounds(shapes[(size_t)sh], lo, hi);
+                for (int a = 0; a < 3; ++a)
+                    CHECK((double)r.bmin[a] <= lo[a] && (double)r.bmax[a] >= hi[a], "leaf box misses shape %d on axis %d", sh, a);
+            }
+        } else {
+            walk(t, r.w0, here, &r, seen, shapes, depth + 1);
+        }
+    }
+}
+
+static void check_scene(const char* name, const std::vector<rt_shape>& shapes, int leaf_size) {
+    for (int kind = 0; kind < 2; ++kind) {
+        const std::vector<HostNode> nodes = kind == 0 ? build_sah(shapes.data(), (int64_t)shapes.size(), leaf_size)
+                                                      : build_octree(shapes.data(), (int64_t)shapes.size());
+        FlatTree t;
+        const char* err = nullptr;
+        CHECK(flatten_octree(nodes, leaf_size, &t, &err), "%s: flatten failed: %s", name, err ? err : "?");
+        std::vector<int> seen(shapes.size(), 0);
+        max_stack = 0;
+        if (!shapes.empty()) walk(t, t.root_ref, 0, nullptr, seen, shapes, 1);
+        for (size_t i = 0; i < shapes.size(); ++i) CHECK(seen[i] == 1, "%s (%s): shape %zu is in %d leaves", name, kind ? "octree" : "sah", i, seen[i]);
+        CHECK(max_stack < t.stack_bound, "%s: walk needs %d stack entries, bound %d", name, max_stack, t.stack_bound);
+        CHECK(t.order.size() == shapes.size(), "%s: order has %zu entries", name, t.order.size());
+        std::printf("%-28s %-6s leaf %d: %6zu shapes %6lld blocks %7zu records depth %2d stack %2d (bound %2d)\n", name, kind ? "octree" : "sah",
+                    leaf_size, shapes.size(), (long long)t.n_inner, t.records.size(), t.depth, max_stack, t.stack_bound);
+    }
+}
+
+int main() {
+    std::mt19937_64 rng(12345);
+    std::uniform_real_distribution<double> u(-1.0, 1.0);
+    auto sphere = [&](double x, double y, double z, double r) { rt_shape s{}; s.kind = RT_SHAPE_SPHERE; s.a = {x, y, z}; s.b = {r, 0, 0}; return s; };
+    auto tri = [&](double x, double y, double z, double e) {
+        rt_shape s{}; s.kind = RT_SHAPE_TRIANGLE;
+        s.a = {x, y, z}; s.b = {x + e * u(rng), y + e * u(rng), z + e * u(rng)}; s.c = {x + e * u(rng), y + e * u(rng), z + e * u(rng)};
+        return s;
+    };
+    for (int leaf : {1, 4, 6, 8}) {
+        check_scene("empty", {}, leaf);
+        check_scene("one sphere", {sphere(0, 0, 0, 1)}, leaf);
+        std::vector<rt_shape> v;
+        for (int i = 0; i < 5000; ++i) v.push_back(i % 3 ? tri(10 * u(rng), 10 * u(rng), 10 * u(rng), 0.3) : sphere(10 * u(rng), 10 * u(rng), 10 * u(rng), 0.2));
+        check_scene("random mix", v, leaf);
+        v.clear();
+        for (int i = 0; i < 300; ++i) v.push_back(sphere(1.0, 2.0, 3.0, 0.5));  // identical centroids
+        check_scene("coincident", v, leaf);
+        v.clear();
+        for (int i = 0; i < 1500; ++i) { const double x = std::pow(1.1, i / 10.0); v.push_back(sphere(x, 0.02 * x * (i % 7 - 3), 0, 0.04 * x)); }
+        check_scene("exponential spacing", v, leaf);
+        v.clear();
+        for (int i = 0; i < 2000; ++i) v.push_back(tri(i * 0.01, 0, 0, 1e-9));  // a line of needle-thin triangles
+        v.push_back(tri(0, 0, 0, 1e3));                                          // and one huge triangle over them
+        check_scene("line + huge", v, leaf);
+    }
+    std::printf(fails ? "%d FAILURES\n" : "all builder invariants hold\n", fails);
+    return fails ? 1 : 0;
+}

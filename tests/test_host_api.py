@@ -127,3 +127,20 @@ def test_sample_split_covers_all_samples():
         for world in (1, 2, 3, 8):
             r = [d.sample_range(spp, k, world) for k in range(world)]
             assert r[0][0] == 0 and r[-1][1] == spp and all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+
+
+def test_tree_builders_under_sanitizers(tmp_path):
+    """tests/cpp/builder_check.cpp: both host builders + the flattener on random and degenerate scenes,
+    compiled with AddressSanitizer and UBSan (host code only).  Checks that every shape sits in exactly
+    one leaf, every box encloses what is below it, indices are in range and the exact stack bound holds."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "builder_check"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "builder_check.cpp"),
+                           os.path.join(root, "raytracer-go_amd", "csrc", "octree.cpp"), "-o", str(exe)])
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "all builder invariants hold" in p.stdout
