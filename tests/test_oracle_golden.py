@@ -172,3 +172,21 @@ def test_unit_sphere_sampler_is_uniform_in_the_ball(bridge):
     assert np.abs(np.bincount(octant, minlength=8) / n - 0.125).max() < tol
     z = p[:, 2] / np.sqrt(r2)  # direction: cos(theta) uniform on [-1, 1]
     assert np.abs(np.histogram(z, bins=10, range=(-1, 1))[0] / n - 0.1).max() < tol
+
+
+def test_oracle_under_sanitizers(tmp_path, gold_dir):
+    """tests/cpp/oracle_check.cpp links the oracle source with AddressSanitizer and UBSan and drives every
+    shape / material / light / texture kind through all three modes and both fp32 tree mirrors: a checker
+    with undefined behaviour would be a poor checker.  The harness also asserts DFS == best-first and
+    that the fp32 mirrors stay within tolerance of fp64."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(gold_dir))
+    exe = tmp_path / "oracle_check"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "oracle_check.cpp"),
+                           os.path.join(root, "oracle", "rtgo_oracle.cpp"), "-pthread", "-o", str(exe)])
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "oracle self-check ok" in p.stdout
