@@ -171,7 +171,8 @@ RT_DEV float prim_hit(const DScene& S, uint32_t prim, f3 o, f3 d, float tmin, fl
 
 // ---- optional loop instrumentation (make prof -> librtgo_prof.so, scripts/prof_loops.py) ----
 #ifdef RTGO_PROF
-__device__ unsigned long long g_prof[8];  // [2i] = times a wavefront passed point i, [2i+1] = lanes active there
+__device__ unsigned long long g_prof[8];
+__device__ unsigned long long g_prof2[4];  // shadow-ray flushes: shapes queued in total, largest per-lane count, lanes in the wavefront  // [2i] = times a wavefront passed point i, [2i+1] = lanes active there
 #define RT_PROF_POINT(i)                                                          \
     do {                                                                          \
         const unsigned long long m_ = __ballot(true);                             \
@@ -384,6 +385,26 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
     uint32_t npend = 0;
     uint32_t* const pend = st.lds + kLdsStackDepth * st.lds_stride;
     auto flush = [&]() {
+#ifdef RTGO_PROF
+        {   // per flush: lanes holding leaves, their shapes in total and the largest count of one lane
+            uint32_t mine = 0;
+            for (uint32_t q = 0; q < npend; ++q) mine += pend[q * st.lds_stride] & 0xffu;
+            uint32_t sum = mine, mx = mine;
+            for (int off = 32; off > 0; off >>= 1) {
+                sum += (uint32_t)__shfl_xor((int)sum, off);
+                const uint32_t other = (uint32_t)__shfl_xor((int)mx, off);
+                mx = other > mx ? other : mx;
+            }
+            const unsigned long long m_ = __ballot(true);
+            if ((int)__lane_id() == __ffsll((long long)m_) - 1) {
+                atomicAdd(&g_prof[6], 1ull);
+                atomicAdd(&g_prof[7], (unsigned long long)__popcll(__ballot(npend > 0u)));
+                atomicAdd(&g_prof2[0], (unsigned long long)sum);
+                atomicAdd(&g_prof2[1], (unsigned long long)mx);
+                atomicAdd(&g_prof2[2], (unsigned long long)__popcll(m_));
+            }
+        }
+#endif
         uint32_t qhead = 0, pnext = 0, pleft = 0;
         for (;;) {
             if (pleft == 0) {

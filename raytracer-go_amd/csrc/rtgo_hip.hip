@@ -1095,6 +1095,7 @@ int rt_camera_rays(rt_scene* s, const rt_image_spec* spec, uint64_t seed, const 
 int rt_debug_prof(unsigned long long* out8, int reset) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(rtgo::g_prof), 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyFromSymbol(out8 + 8, HIP_SYMBOL(rtgo::g_prof2), 4 * sizeof(unsigned long long)));  // out8 holds 12
     if (reset) {
         const unsigned long long z[8] = {};
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtgo::g_prof), z, sizeof(z)));

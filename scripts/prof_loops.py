@@ -9,7 +9,7 @@ scenes = importlib.import_module("raytracer-go_amd.scenes")
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1080
 spec, scene = scenes.config3(1920, rows, 64 if rows < 1080 else 16, 16, asset_dir=os.path.join(ROOT, "tests/golden"))
 dev = backend.DeviceScene(scene)
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 12)()
 L = backend.lib()
 acc, st = dev.render_accum(spec)
 L.rt_debug_prof(out, 0)
@@ -20,3 +20,7 @@ print("shadow rays", st.rays_shadow, "ms_shadow %.1f" % st.ms_shadow, "wave roun
 for name, i in (("block visits", 0), ("shape tests", 1)):
     print("%-12s: %.1f per wave round, %.1f per ray, lane utilisation %.2f" %
           (name, v[2 * i] / rounds, v[2 * i + 1] / st.rays_shadow, v[2 * i + 1] / (64.0 * v[2 * i])))
+fl = v[6]
+if fl:
+    print("shadow-ray shape loops: %.2f per wave round; per loop: %.1f lanes hold leaves (of %.1f in the wavefront), %.1f shapes in total, largest lane %.1f -> ideal %.1f iterations if dealt out evenly"
+          % (fl / rounds, v[7] / fl, v[10] / fl, v[8] / fl, v[9] / fl, v[8] / fl / 64.0))
