@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void k_extend(DScene S, Work Wk, const uint
     __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlock;
-    const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride};
+    const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride, nullptr};
     for (uint32_t i = gtid; i < n; i += gstride) {
         const uint32_t slot = queue[i];
         const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
@@ -351,9 +351,10 @@ __global__ __launch_bounds__(kBlock) void k_pair_compact(Work Wk, uint32_t n_hit
 __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, Batch B, Work Wk, uint32_t n_hits, int bounce,
                                                    int group, int group_shift, const uint32_t* pair_counter) {
     __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
+    __shared__ uint32_t s_wave[(kBlock / 64) * 128];
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlock;
-    const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride};
+    const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride, s_wave + (threadIdx.x >> 6) * 128};
     const unsigned long long total = (unsigned long long)(*pair_counter) * group;  // written by k_pair_offsets, same stream
     const unsigned long long rounds = (total + gstride - 1) / gstride;
     const int lane = (int)__lane_id();
@@ -404,7 +405,9 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
                 }
             }
             RT_PROF_POINT(2);  // shadow-ray rounds
-            if (traced) vis = !occluded(S, st, p, dir, 0.01f, dist);
+            // all 64 lanes call: lanes without a ray of their own test shapes for the others
+            const bool occ = occluded(S, st, traced, p, dir, 0.01f, dist);
+            vis = traced && !occ;
             const unsigned long long m = __ballot(vis);
             count += (uint32_t)__popcll(m & gmask);
         }
@@ -471,15 +474,19 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float* accum, int n_pi
 __global__ __launch_bounds__(kBlock) void k_trace_probe(DScene S, Work Wk, const float* rays, uint32_t n, int any_hit,
                                                         int* prim_out, float* t_out) {
     __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
+    __shared__ uint32_t s_wave[(kBlock / 64) * 128];
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlock;
-    const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride};
-    for (uint32_t i = gtid; i < n; i += gstride) {
-        const float* q = rays + (size_t)i * 8;
+    const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride, s_wave + (threadIdx.x >> 6) * 128};
+    // wave-uniform trip count: occluded() needs all 64 lanes of a wavefront
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gstride) {
+        const uint32_t i = base + threadIdx.x;
+        const bool live = i < n;
+        const float* q = rays + (size_t)(live ? i : 0u) * 8;
         if (any_hit) {
-            prim_out[i] = occluded(S, st, mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), q[6], q[7]) ? 1 : 0;
-            t_out[i] = 0.0f;
-        } else {
+            const bool occ = occluded(S, st, live, mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), q[6], q[7]);
+            if (live) { prim_out[i] = occ ? 1 : 0; t_out[i] = 0.0f; }
+        } else if (live) {
             float t; int prim;
             traverse(S, st, mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), q[6], &t, &prim);
             prim_out[i] = prim >= 0 ? S.prim_ids[prim] : -1;  // report the position in Scene.Shapes
