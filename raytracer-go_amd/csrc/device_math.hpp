@@ -250,10 +250,11 @@ RT_DEV void visit_block(const DScene& S, uint32_t cur, const TraceRay& r, float 
         ra[k] = S.recs[2 * idx];
         rb[k] = S.recs[2 * idx + 1];
     }
-    uint32_t lm = 0, im = 0;
+    // leaf mask of this block in octant order (every record of a block carries it; the first is always there)
+    const uint32_t leaves = __float_as_uint(S.recs[2 * (size_t)first + 1].w);
+    uint32_t hit = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {  // no branch per slot: an absent slot's result is masked out
-        const uint32_t oct = (uint32_t)k ^ r.sign;
+    for (int k = 0; k < 8; ++k) {  // no branch per slot: an absent slot's result is masked out below
         const float4 a = ra[k], b = rb[k];
         float tn = t_enter, tf = entry_best;
         {
@@ -268,14 +269,19 @@ RT_DEV void visit_block(const DScene& S, uint32_t cur, const TraceRay& r, float 
             const float lo = fmaf(a.z, r.inv.z, -r.oi.z), hi = fmaf(b.y, r.inv.z, -r.oi.z);
             tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
         }
-        const uint32_t hit = (((present >> oct) & 1u) != 0u && tn <= tf) ? (1u << k) : 0u;
+        hit |= tn <= tf ? (1u << k) : 0u;
         ref[k] = __float_as_uint(b.z);
-        const bool is_leaf = (__float_as_uint(b.w) & kLeaf) != 0u;
-        lm |= is_leaf ? hit : 0u;
-        im |= is_leaf ? 0u : hit;
     }
-    *leaf_mask = lm;
-    *inner_mask = im;
+    // present and leaf masks are in octant order; ray-order position k holds octant k ^ sign, and that
+    // permutation of the bits is three conditional swaps (halves, pairs, neighbours) of both masks at once
+    uint32_t m = present | ((leaves & 0xffu) << 8);
+    const uint32_t s4 = r.sign & 4u, s2 = r.sign & 2u, s1 = r.sign & 1u;
+    m = ((m >> s4) & 0x0f0fu) | ((m << s4) & 0xf0f0u);
+    m = ((m >> s2) & 0x3333u) | ((m << s2) & 0xccccu);
+    m = ((m >> s1) & 0x5555u) | ((m << s1) & 0xaaaau);
+    hit &= m;  // (bits 8..15 of hit are zero)
+    *leaf_mask = hit & (m >> 8);
+    *inner_mask = hit & ~(m >> 8);
 }
 // (2): branch-free append in ray order — every slot stores at the queue's end, which only moves for hit leaves
 RT_DEV void queue_leaves(uint32_t* pend, uint32_t stride, const uint32_t ref[8], uint32_t leaf_mask, uint32_t* npend) {

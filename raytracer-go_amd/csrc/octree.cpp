@@ -437,6 +437,7 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
         ChildRecord r;
         set_box(root, &r);
         make_leaf(root, &r);
+        r.w1 |= 1u;
         out->records.push_back(r);
         out->root_ref = (0u << 8) | 1u;
         out->n_inner = 1; out->depth = 1; out->stack_bound = 8;
@@ -450,7 +451,7 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
         const int64_t first = (int64_t)out->records.size();
         int32_t slot[8];
         block_slots(nodes, p.node, leaf_size, slot);
-        uint32_t present = 0;
+        uint32_t present = 0, leaf_mask = 0;
         for (int o = 0; o < 8; ++o) {
             const int32_t e = slot[o];
             if (e < 0) continue;
@@ -459,6 +460,7 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
             set_box(e, &r);
             if (nodes[e].n_shapes <= leaf_size) {
                 make_leaf(e, &r);
+                leaf_mask |= 1u << o;
             } else {
                 r.w0 = 0; r.w1 = 0;
                 queue.push_back({e, (int64_t)out->records.size(), p.level + 1});
@@ -466,6 +468,7 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
             out->records.push_back(r);
         }
         (void)nd;
+        for (size_t k = (size_t)first; k < out->records.size(); ++k) out->records[k].w1 |= leaf_mask;
         if ((int64_t)out->records.size() > kMaxChildRecords || (int64_t)out->order.size() >= kMaxChildRecords) {
             *err = "scene too large: the flattened octree exceeds 2^24 child records";
             return false;

@@ -16,8 +16,9 @@
 //     (depth-first, octant order); shapes are re-ordered so that a leaf's shapes are contiguous
 //     (`order[q]` = position in Scene.Shapes of re-ordered shape q).  leaf_size = 1 keeps the
 //     reference's one-shape-per-leaf tree;
-//   - inner child : w0 = (first record of its block << 8) | 8-bit octant-present mask, w1 = 0
-//     leaf child  : w0 = (first re-ordered shape << 8) | shape count, w1 = kLeafFlag.
+//   - inner child : w0 = (first record of its block << 8) | 8-bit octant-present mask, w1 = 0 (+ mask below)
+//     leaf child  : w0 = (first re-ordered shape << 8) | shape count, w1 = kLeafFlag;
+//     every record's w1 also holds, in its low 8 bits, the leaf mask of the block it is in (octant order).
 #pragma once
 #include <cstdint>
 #include <vector>
