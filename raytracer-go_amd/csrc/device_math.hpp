@@ -378,6 +378,32 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
     return best_prim >= 0;
 }
 
+// Inclusive scans over the 64 lanes of a wavefront through the DPP path (shifts within rows of 16 lanes,
+// then the last lane of a row broadcast to the rows after it); every lane of the wavefront must be active.
+template <int CTRL, int ROWS>
+RT_DEV uint32_t dpp_or_zero(uint32_t x) {  // lanes that get no source, or whose row is masked out, read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWS, 0xf, false);
+}
+RT_DEV uint32_t wave_scan_add(uint32_t x) {
+    x += dpp_or_zero<0x111, 0xf>(x);  // row_shr:1
+    x += dpp_or_zero<0x112, 0xf>(x);  // row_shr:2
+    x += dpp_or_zero<0x114, 0xf>(x);  // row_shr:4
+    x += dpp_or_zero<0x118, 0xf>(x);  // row_shr:8
+    x += dpp_or_zero<0x142, 0xa>(x);  // row_bcast:15 into rows 1 and 3
+    x += dpp_or_zero<0x143, 0xc>(x);  // row_bcast:31 into rows 2 and 3
+    return x;
+}
+RT_DEV uint32_t wave_scan_max(uint32_t x) {
+    uint32_t y;
+    y = dpp_or_zero<0x111, 0xf>(x); x = x > y ? x : y;
+    y = dpp_or_zero<0x112, 0xf>(x); x = x > y ? x : y;
+    y = dpp_or_zero<0x114, 0xf>(x); x = x > y ? x : y;
+    y = dpp_or_zero<0x118, 0xf>(x); x = x > y ? x : y;
+    y = dpp_or_zero<0x142, 0xa>(x); x = x > y ? x : y;
+    y = dpp_or_zero<0x143, 0xc>(x); x = x > y ? x : y;
+    return x;
+}
+
 // Shadow rays: "is anything hit with tmin <= t <= tmax" (doesReachLight, light.go:141-160); the first
 // accepted hit ends the ray.  Same walk and leaf queue as traverse().
 // (Dealing the queued leaves out evenly over all 64 lanes — prefix sum, owner search, cross-lane ray
@@ -396,34 +422,31 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
     uint32_t npend = 0;
     uint32_t* const pend = st.lds + kLdsStackDepth * st.lds_stride;
     const int lane = (int)__lane_id();
-    uint32_t* const incl = st.wave;        // inclusive prefix sums of the lanes' queued shape counts
+    uint32_t* const own = st.wave;         // per item of a round: (round stamp << 6) | owner lane where an owner's shapes begin
     uint32_t* const flag = st.wave + 64;   // per owner lane: one of its queued shapes was hit
+    uint32_t stamp = 0;                    // rounds so far: entries of earlier rounds lose against this round's
+    own[lane] = 0u;
 
     auto flush = [&]() {
         uint32_t mine = 0;
         for (uint32_t q = 0; q < npend; ++q) mine += pend[q * st.lds_stride] & 0xffu;
-        uint32_t sum = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = (uint32_t)__shfl_up((int)sum, off);
-            if (lane >= off) sum += v;
-        }
+        const uint32_t sum = wave_scan_add(mine);  // this lane's shapes are items [sum - mine, sum) of the wavefront
+        const uint32_t excl = sum - mine;
         const uint32_t total = (uint32_t)__shfl((int)sum, 63);
-        incl[lane] = sum;
         flag[lane] = 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (uint32_t base = 0; base < total; base += 64u) {
+            // every lane whose items reach into this round marks where they begin; the owner of an item is the
+            // last mark at or before it (item 0 always has one: the lane whose items span `base`)
+            ++stamp;
+            if (mine != 0u && sum > base && excl < base + 64u) own[excl > base ? excl - base : 0u] = (stamp << 6) | (uint32_t)lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const uint32_t item = base + (uint32_t)lane;
             const bool has = item < total;
-            int owner = 0;  // smallest lane whose inclusive sum exceeds item
-#pragma unroll
-            for (int step = 32; step >= 1; step >>= 1)
-                if (incl[owner + step - 1] <= item) owner += step;
-            owner = has ? owner : lane;
-            uint32_t g = has ? item - (owner > 0 ? incl[owner - 1] : 0u) : 0u;  // which of the owner's shapes
-            const uint32_t* const oq = pend + (owner - lane);                      // the owner's queue
+            const int owner = (int)(wave_scan_max(own[lane]) & 63u);
+            uint32_t g = item - (uint32_t)__shfl((int)excl, owner);  // which of the owner's shapes
+            const uint32_t* const oq = pend + (owner - lane);          // the owner's queue
             uint32_t shape = 0;
             if (has) {
                 uint32_t leaf = oq[0];
