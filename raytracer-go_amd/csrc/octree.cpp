@@ -7,6 +7,9 @@
 #include <cstdlib>
 #include <deque>
 #include <unordered_map>
+#include <atomic>
+#include <memory>
+#include <thread>
 
 namespace rtgo {
 namespace {
@@ -173,63 +176,126 @@ std::vector<HostNode> build_octree(const rt_shape* shapes, int64_t n) {
 // ---- binned-SAH BVH emitted in the same 8-slot HostNode form (the default tree; spec in octree.hpp) ----
 namespace {
 struct SahItem { double lo[3], hi[3], c[3]; int32_t shape; };
-struct Bvh2 { double lo[3], hi[3]; int32_t left = -1, right = -1, b = 0, e = 0; };
+struct Bvh2 { double lo[3], hi[3]; int32_t left, right, b, e; };
 double area3(const double lo[3], const double hi[3]) {
     const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
     return 2.0 * ((dx * dy + dy * dz) + dz * dx);
 }
 constexpr int kMaxSahDepth = 48;
+constexpr int32_t kParallelMin = 16384;  // ranges at least this long may be split off to a thread of their own
+constexpr int32_t kChunkMin = 131072;    // ranges at least this long are swept by several threads
 struct SahBuilder {
     std::vector<SahItem> items;
-    std::vector<Bvh2> b2;
+    std::unique_ptr<SahItem[]> tmp;    // same length as items: a range's right half while it is being split
+    std::unique_ptr<Bvh2[]> b2;        // 2n - 1 nodes at most (every leaf holds a shape); numbered as they are made
+    std::atomic<int32_t> n_nodes{0};
     int leaf_size;
     // depth: SAH may split 1 : n-1 again and again on adversarial input; beyond kMaxSahDepth levels the
-    // range is halved instead, so the recursion stays O(kMaxSahDepth + log n) deep
-    int32_t build(int32_t b, int32_t e, int depth = 0) {
+    // range is halved instead, so the recursion stays O(kMaxSahDepth + log n) deep.
+    // threads: how many threads this subtree may use; a split shares them out by the halves' lengths.  The
+    // two halves of a range touch disjoint items and only the node numbers depend on the interleaving;
+    // emit() follows left/right links, so the tree that comes out is the same for any number of threads.
+    static constexpr int kBins = 16;
+    struct Bin { double lo[3], hi[3]; int n; };
+    struct Pass {  // what one chunk of a range contributes to the passes over it
+        double lo[3], hi[3], clo[3], chi[3];
+        Bin bins[3][kBins];
+        int32_t n_left;
+    };
+    // f(chunk, first, last) over nt equal chunks of [b, e), chunk 0 on the calling thread
+    template <class F>
+    static void chunks(int32_t b, int32_t e, int nt, F&& f) {
+        if (nt <= 1) { f(0, b, e); return; }
+        const int64_t len = e - b;
+        std::vector<std::thread> th;
+        for (int c = 1; c < nt; ++c)
+            th.emplace_back([&f, b, len, nt, c] { f(c, b + (int32_t)(len * c / nt), b + (int32_t)(len * (c + 1) / nt)); });
+        f(0, b, b + (int32_t)(len / nt));
+        for (auto& t : th) t.join();
+    }
+    int32_t build(int32_t b, int32_t e, int depth, int threads) {
+        // a long range is swept by all the threads this subtree may use; min, max and counts merge exactly,
+        // so the chunking changes no value
+        const int nt = (e - b >= kChunkMin) ? threads : 1;
+        Pass one;
+        std::vector<Pass> many;
+        Pass* ps = &one;
+        if (nt > 1) { many.resize((size_t)nt); ps = many.data(); }
+
+        chunks(b, e, nt, [&](int c, int32_t cb, int32_t ce) {
+            Pass& p = ps[c];
+            for (int a = 0; a < 3; ++a) { p.lo[a] = p.clo[a] = DBL_MAX; p.hi[a] = p.chi[a] = -DBL_MAX; }
+            for (int32_t i = cb; i < ce; ++i)
+                for (int a = 0; a < 3; ++a) {
+                    p.lo[a] = std::fmin(p.lo[a], items[i].lo[a]); p.hi[a] = std::fmax(p.hi[a], items[i].hi[a]);
+                    p.clo[a] = std::fmin(p.clo[a], items[i].c[a]); p.chi[a] = std::fmax(p.chi[a], items[i].c[a]);
+                }
+        });
         Bvh2 nd;
-        nd.b = b; nd.e = e;
+        nd.b = b; nd.e = e; nd.left = nd.right = -1;
         double clo[3], chi[3];
         for (int a = 0; a < 3; ++a) { nd.lo[a] = clo[a] = DBL_MAX; nd.hi[a] = chi[a] = -DBL_MAX; }
-        for (int32_t i = b; i < e; ++i)
+        for (int c = 0; c < nt; ++c)
             for (int a = 0; a < 3; ++a) {
-                nd.lo[a] = std::fmin(nd.lo[a], items[i].lo[a]); nd.hi[a] = std::fmax(nd.hi[a], items[i].hi[a]);
-                clo[a] = std::fmin(clo[a], items[i].c[a]); chi[a] = std::fmax(chi[a], items[i].c[a]);
+                nd.lo[a] = std::fmin(nd.lo[a], ps[c].lo[a]); nd.hi[a] = std::fmax(nd.hi[a], ps[c].hi[a]);
+                clo[a] = std::fmin(clo[a], ps[c].clo[a]); chi[a] = std::fmax(chi[a], ps[c].chi[a]);
             }
-        const int32_t me = (int32_t)b2.size();
-        b2.push_back(nd);
+        const int32_t me = n_nodes.fetch_add(1, std::memory_order_relaxed);
+        b2[me] = nd;
         if (e - b <= leaf_size) return me;
-        constexpr int kBins = 16;
+
+        bool use[3]; double scale[3];
+        bool any = false;
+        for (int a = 0; a < 3; ++a) {
+            const double ext = chi[a] - clo[a];
+            use[a] = depth < kMaxSahDepth && ext > 0;
+            scale[a] = use[a] ? kBins / ext : 0;
+            any = any || use[a];
+        }
         int best_axis = -1, best_split = 0;
         double best_cost = DBL_MAX;
-        for (int a = 0; a < 3 && depth < kMaxSahDepth; ++a) {
-            const double ext = chi[a] - clo[a];
-            if (!(ext > 0)) continue;
-            struct Bin { double lo[3], hi[3]; int n; } bins[kBins];
-            for (auto& bn : bins) { bn.n = 0; for (int k = 0; k < 3; ++k) { bn.lo[k] = DBL_MAX; bn.hi[k] = -DBL_MAX; } }
-            const double scale = kBins / ext;
-            for (int32_t i = b; i < e; ++i) {
-                int k = (int)((items[i].c[a] - clo[a]) * scale);  // coordinates are finite (checked at scene creation)
-                if (k >= kBins) k = kBins - 1;
-                if (k < 0) k = 0;
-                bins[k].n++;
-                for (int q = 0; q < 3; ++q) { bins[k].lo[q] = std::fmin(bins[k].lo[q], items[i].lo[q]); bins[k].hi[q] = std::fmax(bins[k].hi[q], items[i].hi[q]); }
-            }
-            double ra[kBins]; int rn[kBins];
-            double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
-            int cnt = 0;
-            for (int k = kBins - 1; k >= 1; --k) {
-                for (int q = 0; q < 3; ++q) { lo[q] = std::fmin(lo[q], bins[k].lo[q]); hi[q] = std::fmax(hi[q], bins[k].hi[q]); }
-                cnt += bins[k].n;
-                ra[k] = cnt ? area3(lo, hi) : 0; rn[k] = cnt;
-            }
-            for (int q = 0; q < 3; ++q) { lo[q] = DBL_MAX; hi[q] = -DBL_MAX; }
-            cnt = 0;
-            for (int k = 0; k < kBins - 1; ++k) {
-                for (int q = 0; q < 3; ++q) { lo[q] = std::fmin(lo[q], bins[k].lo[q]); hi[q] = std::fmax(hi[q], bins[k].hi[q]); }
-                cnt += bins[k].n;
-                if (cnt == 0 || rn[k + 1] == 0) continue;
-                const double cost = area3(lo, hi) * cnt + ra[k + 1] * rn[k + 1];
-                if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = k; }
+        if (any) {
+            chunks(b, e, nt, [&](int c, int32_t cb, int32_t ce) {  // the three axes' bins in one sweep
+                Pass& p = ps[c];
+                for (int a = 0; a < 3; ++a)
+                    for (auto& bn : p.bins[a]) { bn.n = 0; for (int k = 0; k < 3; ++k) { bn.lo[k] = DBL_MAX; bn.hi[k] = -DBL_MAX; } }
+                for (int32_t i = cb; i < ce; ++i)
+                    for (int a = 0; a < 3; ++a) {
+                        if (!use[a]) continue;
+                        int k = (int)((items[i].c[a] - clo[a]) * scale[a]);  // coordinates are finite (checked at scene creation)
+                        if (k >= kBins) k = kBins - 1;
+                        if (k < 0) k = 0;
+                        Bin& bn = p.bins[a][k];
+                        bn.n++;
+                        for (int q = 0; q < 3; ++q) { bn.lo[q] = std::fmin(bn.lo[q], items[i].lo[q]); bn.hi[q] = std::fmax(bn.hi[q], items[i].hi[q]); }
+                    }
+            });
+            for (int a = 0; a < 3; ++a) {
+                if (!use[a]) continue;
+                Bin* bins = ps[0].bins[a];
+                for (int c = 1; c < nt; ++c)
+                    for (int k = 0; k < kBins; ++k) {
+                        const Bin& o = ps[c].bins[a][k];
+                        bins[k].n += o.n;
+                        for (int q = 0; q < 3; ++q) { bins[k].lo[q] = std::fmin(bins[k].lo[q], o.lo[q]); bins[k].hi[q] = std::fmax(bins[k].hi[q], o.hi[q]); }
+                    }
+                double ra[kBins]; int rn[kBins];
+                double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+                int cnt = 0;
+                for (int k = kBins - 1; k >= 1; --k) {
+                    for (int q = 0; q < 3; ++q) { lo[q] = std::fmin(lo[q], bins[k].lo[q]); hi[q] = std::fmax(hi[q], bins[k].hi[q]); }
+                    cnt += bins[k].n;
+                    ra[k] = cnt ? area3(lo, hi) : 0; rn[k] = cnt;
+                }
+                for (int q = 0; q < 3; ++q) { lo[q] = DBL_MAX; hi[q] = -DBL_MAX; }
+                cnt = 0;
+                for (int k = 0; k < kBins - 1; ++k) {
+                    for (int q = 0; q < 3; ++q) { lo[q] = std::fmin(lo[q], bins[k].lo[q]); hi[q] = std::fmax(hi[q], bins[k].hi[q]); }
+                    cnt += bins[k].n;
+                    if (cnt == 0 || rn[k + 1] == 0) continue;
+                    const double cost = area3(lo, hi) * cnt + ra[k + 1] * rn[k + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = k; }
+                }
             }
         }
         int32_t mid;
@@ -237,17 +303,52 @@ struct SahBuilder {
             mid = b + (e - b) / 2;  // all centroids coincide
         } else {
             const int a = best_axis;
-            const double scale = kBins / (chi[a] - clo[a]);
-            auto it = std::stable_partition(items.begin() + b, items.begin() + e, [&](const SahItem& s) {
-                int k = (int)((s.c[a] - clo[a]) * scale);
+            const double sc = scale[a];
+            auto goes_left = [&](const SahItem& it) {
+                int k = (int)((it.c[a] - clo[a]) * sc);
                 if (k >= kBins) k = kBins - 1;
                 return k <= best_split;
-            });
-            mid = (int32_t)(it - items.begin());
+            };
+            if (nt == 1) {
+                // stable split in place: left items close up, right items wait in tmp[b..] (the same range, so
+                // threads working on disjoint ranges do not meet) and are copied back behind them
+                int32_t nl = b, nr = b;
+                for (int32_t i = b; i < e; ++i)
+                    if (goes_left(items[i])) items[nl++] = items[i]; else tmp[nr++] = items[i];
+                std::copy(tmp.get() + b, tmp.get() + nr, items.begin() + nl);
+                mid = nl;
+            } else {
+                // the same split by chunks: count, then every chunk writes its left and right items to their
+                // final places in tmp[b, e), then the range is copied back
+                chunks(b, e, nt, [&](int c, int32_t cb, int32_t ce) {
+                    int32_t n = 0;
+                    for (int32_t i = cb; i < ce; ++i) n += goes_left(items[i]) ? 1 : 0;
+                    ps[c].n_left = n;
+                });
+                int32_t total_left = 0;
+                for (int c = 0; c < nt; ++c) total_left += ps[c].n_left;
+                chunks(b, e, nt, [&](int c, int32_t cb, int32_t ce) {
+                    int32_t nl = b, nr = b + total_left + (cb - b);
+                    for (int k = 0; k < c; ++k) { nl += ps[k].n_left; nr -= ps[k].n_left; }
+                    for (int32_t i = cb; i < ce; ++i)
+                        if (goes_left(items[i])) tmp[nl++] = items[i]; else tmp[nr++] = items[i];
+                });
+                chunks(b, e, nt, [&](int, int32_t cb, int32_t ce) { std::copy(tmp.get() + cb, tmp.get() + ce, items.begin() + cb); });
+                mid = b + total_left;
+            }
             if (mid == b || mid == e) mid = b + (e - b) / 2;
         }
-        const int32_t l = build(b, mid, depth + 1);
-        const int32_t r = build(mid, e, depth + 1);
+        int32_t l, r;
+        if (threads > 1 && mid - b >= kParallelMin && e - mid >= kParallelMin) {
+            int tl = (int)(((int64_t)threads * (mid - b) + (e - b) / 2) / (e - b));
+            tl = tl < 1 ? 1 : (tl > threads - 1 ? threads - 1 : tl);
+            std::thread left([&] { l = build(b, mid, depth + 1, tl); });
+            r = build(mid, e, depth + 1, threads - tl);
+            left.join();
+        } else {  // a short half is not worth a thread: the long one keeps them all
+            l = build(b, mid, depth + 1, mid - b >= e - mid ? threads : 1);
+            r = build(mid, e, depth + 1, mid - b >= e - mid ? 1 : threads);
+        }
         b2[me].left = l; b2[me].right = r;
         return me;
     }
@@ -287,16 +388,22 @@ struct SahBuilder {
         for (int a = 0; a < 3; ++a) m[a] = (nd.lo[a] + nd.hi[a]) * 0.5;
         int32_t slot[8]; for (int& x : slot) x = -1;
         bool placed[8] = {};
+        double score[8][8];  // child i in slot sl
+        for (int i = 0; i < nk; ++i) {
+            const Bvh2& c = b2[kids[i]];
+            for (int sl = 0; sl < 8; ++sl) {
+                double sc = 0;
+                for (int a = 0; a < 3; ++a) sc += ((sl >> a) & 1 ? 1.0 : -1.0) * ((c.lo[a] + c.hi[a]) * 0.5 - m[a]);
+                score[i][sl] = sc;
+            }
+        }
         for (int round = 0; round < nk; ++round) {
             int bi = -1, bs = -1; double bsc = 0;
             for (int i = 0; i < nk; ++i) {
                 if (placed[i]) continue;
-                const Bvh2& c = b2[kids[i]];
                 for (int sl = 0; sl < 8; ++sl) {
                     if (slot[sl] >= 0) continue;
-                    double sc = 0;
-                    for (int a = 0; a < 3; ++a) sc += ((sl >> a) & 1 ? 1.0 : -1.0) * ((c.lo[a] + c.hi[a]) * 0.5 - m[a]);
-                    if (bi < 0 || sc > bsc) { bi = i; bs = sl; bsc = sc; }
+                    if (bi < 0 || score[i][sl] > bsc) { bi = i; bs = sl; bsc = score[i][sl]; }
                 }
             }
             slot[bs] = kids[bi]; placed[bi] = true;
@@ -312,14 +419,24 @@ std::vector<HostNode> build_sah(const rt_shape* shapes, int64_t n, int leaf_size
     if (n == 0) { out.push_back(HostNode{}); return out; }
     SahBuilder sb;
     sb.leaf_size = leaf_size < 1 ? 1 : (leaf_size > 8 ? 8 : leaf_size);
+    // threads building at one time: RTGO_BUILD_THREADS, by default the hardware's but at most 16 (one GPU's
+    // share of a node's cores)
+    int threads = (int)std::thread::hardware_concurrency();
+    if (threads > 16) threads = 16;
+    if (const char* ev = std::getenv("RTGO_BUILD_THREADS")) threads = std::atoi(ev);
+    threads = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
     sb.items.resize((size_t)n);
-    for (int64_t i = 0; i < n; ++i) {
-        SahItem& it = sb.items[(size_t)i];
-        shape_bounds(shapes[i], it.lo, it.hi);
-        for (int a = 0; a < 3; ++a) it.c[a] = (it.lo[a] + it.hi[a]) * 0.5;
-        it.shape = (int32_t)i;
-    }
-    sb.build(0, (int32_t)n);
+    SahBuilder::chunks(0, (int32_t)n, n >= kChunkMin ? threads : 1, [&](int, int32_t cb, int32_t ce) {
+        for (int32_t i = cb; i < ce; ++i) {
+            SahItem& it = sb.items[(size_t)i];
+            shape_bounds(shapes[i], it.lo, it.hi);
+            for (int a = 0; a < 3; ++a) it.c[a] = (it.lo[a] + it.hi[a]) * 0.5;
+            it.shape = i;
+        }
+    });
+    sb.b2.reset(new Bvh2[2 * (size_t)n]);
+    sb.tmp.reset(new SahItem[(size_t)n]);
+    sb.build(0, (int32_t)n, 0, threads);
     out.reserve((size_t)n * 3);
     out.push_back(HostNode{});
     sb.emit(out, 0, 0);

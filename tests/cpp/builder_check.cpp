@@ -5,10 +5,13 @@
 //   - a leaf record's box encloses the bounds of the leaf's shapes, an inner record's box encloses
 //     every record of its block (so no ray can miss a shape by culling a box);
 //   - record / block indices are in range, blocks hold 1..8 records in slot order;
-//   - walking the blocks depth-first never needs more stack than FlatTree::stack_bound.
+//   - walking the blocks depth-first never needs more stack than FlatTree::stack_bound;
+//   - the SAH tree of a scene long enough for the builder's threads (chunked sweeps and forked halves) is
+//     byte-identical for 1, 3 and 7 threads.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -109,6 +112,26 @@ int main() {
         for (int i = 0; i < 2000; ++i) v.push_back(tri(i * 0.01, 0, 0, 1e-9));  // a line of needle-thin triangles
         v.push_back(tri(0, 0, 0, 1e3));                                          // and one huge triangle over them
         check_scene("line + huge", v, leaf);
+    }
+    {
+        std::vector<rt_shape> v;
+        for (int i = 0; i < 300000; ++i) {  // two clusters of unequal size: uneven splits near the root
+            const double off = i % 5 ? 0.0 : 40.0;
+            v.push_back(i % 11 ? tri(off + 10 * u(rng), 10 * u(rng), 10 * u(rng), 0.05) : sphere(off + 10 * u(rng), 10 * u(rng), 10 * u(rng), 0.03));
+        }
+        FlatTree ref;
+        for (const char* threads : {"1", "3", "7"}) {
+            setenv("RTGO_BUILD_THREADS", threads, 1);
+            FlatTree t;
+            const char* err = nullptr;
+            CHECK(flatten_octree(build_sah(v.data(), (int64_t)v.size(), 6), 6, &t, &err), "flatten failed: %s", err ? err : "?");
+            if (threads[0] == '1') { ref = t; continue; }
+            CHECK(t.records.size() == ref.records.size() && t.order == ref.order && t.root_ref == ref.root_ref && t.stack_bound == ref.stack_bound &&
+                      std::memcmp(t.records.data(), ref.records.data(), t.records.size() * sizeof(ChildRecord)) == 0,
+                  "SAH tree differs between 1 and %s threads", threads);
+        }
+        unsetenv("RTGO_BUILD_THREADS");
+        check_scene("two clusters, threaded", v, 6);
     }
     std::printf(fails ? "%d FAILURES\n" : "all builder invariants hold\n", fails);
     return fails ? 1 : 0;

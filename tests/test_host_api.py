@@ -137,7 +137,7 @@ def test_tree_builders_under_sanitizers(tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = tmp_path / "builder_check"
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-pthread",
                            "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
                            os.path.join(root, "tests", "cpp", "builder_check.cpp"),
                            os.path.join(root, "raytracer-go_amd", "csrc", "octree.cpp"), "-o", str(exe)])
