@@ -295,34 +295,25 @@ RT_DEV void queue_leaves(uint32_t* pend, uint32_t stride, const uint32_t ref[8],
         *npend = n;
     }
 }
-// (3): far-to-near pushes of every hit inner child but the nearest, which becomes `cur`; with no hit
-// inner child the next block comes off the stack.  Returns false when there is no next block.
+// (3): far-to-near pushes of every hit inner child; the next block is the top of the stack, i.e. the nearest
+// of them, or an older entry when none was hit (so the stack holds one entry more than
+// FlatTree::stack_bound for a moment).  Returns false when there is no next block.
 RT_DEV bool next_block(const TraceStack& st, const uint32_t ref[8], uint32_t inner_mask, uint32_t* cur, int* sp_io) {
     int sp = *sp_io;
     if (inner_mask) {
-        const uint32_t rest = inner_mask & (inner_mask - 1u);
-        if (sp + 7 <= kLdsStackDepth) {
+        if (sp + 8 <= kLdsStackDepth) {
             // common case, no branch per entry: every slot stores at the current top and the top only
-            // moves for the slots that were hit (the stores beyond it are overwritten or never read)
+            // moves for the slots that were hit; the nearest is pushed last and popped right away
 #pragma unroll
-            for (int k = 7; k >= 1; --k) {
+            for (int k = 7; k >= 0; --k) {
                 st.lds[sp * st.lds_stride] = ref[k];
-                sp += (int)((rest >> k) & 1u);
+                sp += (int)((inner_mask >> k) & 1u);
             }
         } else {
 #pragma unroll
-            for (int k = 7; k >= 1; --k)
-                if ((rest >> k) & 1u) st.put(sp++, ref[k]);
+            for (int k = 7; k >= 0; --k)
+                if ((inner_mask >> k) & 1u) st.put(sp++, ref[k]);
         }
-        // (static loads first: a select between array elements must not become an indexed load from memory)
-        const uint32_t r0 = ref[0], r1 = ref[1], r2 = ref[2], r3 = ref[3], r4 = ref[4], r5 = ref[5], r6 = ref[6], r7 = ref[7];
-        uint32_t c = r7;
-        c = (inner_mask & 64u) ? r6 : c; c = (inner_mask & 32u) ? r5 : c; c = (inner_mask & 16u) ? r4 : c;
-        c = (inner_mask & 8u) ? r3 : c;  c = (inner_mask & 4u) ? r2 : c;  c = (inner_mask & 2u) ? r1 : c;
-        c = (inner_mask & 1u) ? r0 : c;
-        *cur = c;
-        *sp_io = sp;
-        return true;
     }
     if (sp == 0) return false;
     *cur = st.get(--sp);

@@ -803,7 +803,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     HIP_TRY_S(hipMemcpy(s->d_lights, lights.data(), lights.size() * sizeof(DLight), hipMemcpyHostToDevice));
 
     // traversal stack spill: worst case 7 pending siblings per level, beyond the LDS part
-    const int spill = flat.stack_bound > kLdsStackDepth ? flat.stack_bound - kLdsStackDepth : 0;
+    const int spill = flat.stack_bound + 1 > kLdsStackDepth ? flat.stack_bound + 1 - kLdsStackDepth : 0;  // +1: the nearest child is pushed, then popped
     s->spill = spill;  // the region itself is sized by ensure_overflow() for the grids a call really launches
 
     s->d.recs = (const float4*)s->d_recs; s->d.prims = (const float4*)s->d_prims; s->d.tprims = (const float4*)s->d_tprims; s->d.prim_ids = (const int*)s->d_prim_ids;
