@@ -397,9 +397,9 @@ RT_DEV uint32_t wave_scan_max(uint32_t x) {
 
 // Shadow rays: "is anything hit with tmin <= t <= tmax" (doesReachLight, light.go:141-160); the first
 // accepted hit ends the ray.  Same walk and leaf queue as traverse().
-// (Dealing the queued leaves out evenly over all 64 lanes — prefix sum, owner search, cross-lane ray
-// fetch — was measured: shape-loop utilisation 0.20 -> 0.43, frame 1.31 s -> 1.65 s; the bookkeeping per
-// flush and the extra live registers cost more than the idle lanes.  Branch exp/balanced-shape-loop.)
+// (A first version dealt the queue out LEAF by leaf, at a time when the shape loop still ran after most
+// block visits: utilisation 0.20 -> 0.43 but frame 1.31 s -> 1.65 s, branch exp/balanced-shape-loop.  The
+// form below deals out single shapes and runs 2.3 times per 10 block visits.)
 RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 d, float tmin, float tmax) {
     // Called by ALL 64 lanes of a wavefront (live = this lane has a ray).  The lanes walk their own rays, but
     // the shape loop is shared: the queued shapes of all lanes are dealt out evenly, one shape per lane and
