@@ -352,24 +352,11 @@ struct SahBuilder {
         b2[me].left = l; b2[me].right = r;
         return me;
     }
-    // wide node for Bvh2 node `n` written into HostNode `at`
-    void emit(std::vector<HostNode>& out, int32_t n, int32_t at) {
+    // ---- widening: which Bvh2 nodes become the up-to-8 children of a wide node, and in which slots ----
+    struct Wide { int32_t slot[8]; };
+    std::unique_ptr<Wide[]> wide;  // by Bvh2 node; filled for the inner nodes that end up as wide nodes
+    void choose_slots(int32_t n) {
         const Bvh2& nd = b2[n];
-        for (int a = 0; a < 3; ++a) { out[at].lo[a] = nd.lo[a]; out[at].hi[a] = nd.hi[a]; }
-        out[at].empty = false;
-        out[at].n_shapes = nd.e - nd.b;
-        out[at].shape = -1;
-        const int32_t base = (int32_t)out.size();
-        out[at].child_base = base;
-        out.resize(out.size() + 8);
-        if (nd.left < 0) {  // leaf: one single-shape child per shape
-            for (int32_t i = nd.b; i < nd.e; ++i) {
-                HostNode& c = out[base + (i - nd.b)];
-                for (int a = 0; a < 3; ++a) { c.lo[a] = items[i].lo[a]; c.hi[a] = items[i].hi[a]; }
-                c.shape = items[i].shape; c.empty = false; c.n_shapes = 1;
-            }
-            return;
-        }
         int32_t kids[8]; int nk = 2;
         kids[0] = nd.left; kids[1] = nd.right;
         while (nk < 8) {
@@ -386,7 +373,8 @@ struct SahBuilder {
         }
         double m[3];
         for (int a = 0; a < 3; ++a) m[a] = (nd.lo[a] + nd.hi[a]) * 0.5;
-        int32_t slot[8]; for (int& x : slot) x = -1;
+        int32_t* slot = wide[n].slot;
+        for (int sl = 0; sl < 8; ++sl) slot[sl] = -1;
         bool placed[8] = {};
         double score[8][8];  // child i in slot sl
         for (int i = 0; i < nk; ++i) {
@@ -408,8 +396,51 @@ struct SahBuilder {
             }
             slot[bs] = kids[bi]; placed[bi] = true;
         }
+    }
+    // slots of every wide node below n; subtrees of at most `grain` shapes are left to `later` (the threads)
+    void widen(int32_t n, int32_t grain, std::vector<int32_t>* later) {
+        if (b2[n].left < 0) return;
+        if (later && b2[n].e - b2[n].b <= grain) { later->push_back(n); return; }
+        choose_slots(n);
         for (int sl = 0; sl < 8; ++sl)
-            if (slot[sl] >= 0) emit(out, slot[sl], base + sl);
+            if (wide[n].slot[sl] >= 0) widen(wide[n].slot[sl], grain, later);
+    }
+    void widen_all(int threads) {
+        const int32_t total = n_nodes.load();
+        wide.reset(new Wide[(size_t)total]);
+        const int32_t n_items = b2[0].e - b2[0].b;
+        if (threads <= 1 || n_items < kChunkMin) { widen(0, 0, nullptr); return; }
+        std::vector<int32_t> later;
+        widen(0, n_items / (threads * 8) + 1, &later);
+        std::atomic<size_t> next{0};
+        auto work = [&] {
+            for (size_t i = next.fetch_add(1); i < later.size(); i = next.fetch_add(1)) widen(later[i], 0, nullptr);
+        };
+        std::vector<std::thread> th;
+        for (int c = 1; c < threads; ++c) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+    }
+    // wide node for Bvh2 node `n` written into HostNode `at` (sequential: the order fixes the node numbers)
+    void emit(std::vector<HostNode>& out, int32_t n, int32_t at) {
+        const Bvh2& nd = b2[n];
+        for (int a = 0; a < 3; ++a) { out[at].lo[a] = nd.lo[a]; out[at].hi[a] = nd.hi[a]; }
+        out[at].empty = false;
+        out[at].n_shapes = nd.e - nd.b;
+        out[at].shape = -1;
+        const int32_t base = (int32_t)out.size();
+        out[at].child_base = base;
+        out.resize(out.size() + 8);
+        if (nd.left < 0) {  // leaf: one single-shape child per shape
+            for (int32_t i = nd.b; i < nd.e; ++i) {
+                HostNode& c = out[base + (i - nd.b)];
+                for (int a = 0; a < 3; ++a) { c.lo[a] = items[i].lo[a]; c.hi[a] = items[i].hi[a]; }
+                c.shape = items[i].shape; c.empty = false; c.n_shapes = 1;
+            }
+            return;
+        }
+        for (int sl = 0; sl < 8; ++sl)
+            if (wide[n].slot[sl] >= 0) emit(out, wide[n].slot[sl], base + sl);
     }
 };
 }  // namespace
@@ -439,6 +470,7 @@ std::vector<HostNode> build_sah(const rt_shape* shapes, int64_t n, int leaf_size
     sb.build(0, (int32_t)n, 0, threads);
     out.reserve((size_t)n * 3);
     out.push_back(HostNode{});
+    sb.widen_all(threads);
     sb.emit(out, 0, 0);
     return out;
 }

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -627,6 +628,18 @@ inline int grid_for(unsigned long long n) {
 
 }  // namespace
 
+// f(first, last) over [0, n) in chunks on a few host threads (long tables only)
+template <class F>
+static void host_chunks(int64_t n, F&& f) {
+    int nt = (int)std::thread::hardware_concurrency();
+    nt = nt > 8 ? 8 : (nt < 1 ? 1 : nt);
+    if (n < 65536) nt = 1;
+    std::vector<std::thread> th;
+    for (int c = 1; c < nt; ++c) th.emplace_back([&f, n, nt, c] { f(n * c / nt, n * (c + 1) / nt); });
+    f(0, n / nt);
+    for (auto& t : th) t.join();
+}
+
 extern "C" {
 
 const char* rt_last_error(void) { return g_err.c_str(); }
@@ -697,33 +710,31 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
         if (!flatten_octree(nodes, leaf_size, &flat, &err)) return fail(RT_ERR_LIMIT, err);
     }
     // shapes -> 3 float4 each, narrowed to fp32 (round to nearest), stored in leaf order
-    std::vector<float> prims((size_t)desc->n_shapes * 12 + 12, 0.0f);
-    for (int64_t q = 0; q < desc->n_shapes; ++q) {
-        const rt_shape& s = desc->shapes[flat.order[(size_t)q]];
-        float* p = prims.data() + (size_t)q * 12;
-        uint32_t bits = (uint32_t)s.material << 2;
-        if (s.kind == RT_SHAPE_TRIANGLE) {
-            bits |= kPrimTriangle | (s.single_sided ? kPrimSingleSided : 0u);
-            p[0] = (float)s.a.x; p[1] = (float)s.a.y; p[2] = (float)s.a.z;
-            p[3] = (float)s.b.x; p[4] = (float)s.b.y; p[5] = (float)s.b.z;
-            p[6] = (float)s.c.x; p[7] = (float)s.c.y; p[8] = (float)s.c.z;
-        } else {
-            p[0] = (float)s.a.x; p[1] = (float)s.a.y; p[2] = (float)s.a.z; p[3] = (float)s.b.x;
-        }
-        std::memcpy(&p[9], &bits, 4);
-    }
-    // the same records for the intersection tests, with the triangle's edges e1 = B - A, e2 = C - A (fp32
+    // tprims: the same records for the intersection tests, with the triangle's edges e1 = B - A, e2 = C - A (fp32
     // differences of the fp32 vertices, exactly what the tests would compute) in place of B and C
-    std::vector<float> tprims(prims);
-    for (int64_t q = 0; q < desc->n_shapes; ++q) {
-        float* p = tprims.data() + (size_t)q * 12;
-        uint32_t bits;
-        std::memcpy(&bits, &p[9], 4);
-        if (!(bits & kPrimTriangle)) continue;
-        const float ax = p[0], ay = p[1], az = p[2];
-        p[6] = p[6] - ax; p[7] = p[7] - ay; p[8] = p[8] - az;
-        p[3] = p[3] - ax; p[4] = p[4] - ay; p[5] = p[5] - az;
-    }
+    std::vector<float> prims((size_t)desc->n_shapes * 12 + 12, 0.0f), tprims((size_t)desc->n_shapes * 12 + 12, 0.0f);
+    host_chunks(desc->n_shapes, [&](int64_t q0, int64_t q1) {
+        for (int64_t q = q0; q < q1; ++q) {
+            const rt_shape& s = desc->shapes[flat.order[(size_t)q]];
+            float* p = prims.data() + (size_t)q * 12;
+            float* t = tprims.data() + (size_t)q * 12;
+            uint32_t bits = (uint32_t)s.material << 2;
+            if (s.kind == RT_SHAPE_TRIANGLE) {
+                bits |= kPrimTriangle | (s.single_sided ? kPrimSingleSided : 0u);
+                p[0] = (float)s.a.x; p[1] = (float)s.a.y; p[2] = (float)s.a.z;
+                p[3] = (float)s.b.x; p[4] = (float)s.b.y; p[5] = (float)s.b.z;
+                p[6] = (float)s.c.x; p[7] = (float)s.c.y; p[8] = (float)s.c.z;
+                t[0] = p[0]; t[1] = p[1]; t[2] = p[2];
+                t[3] = p[3] - p[0]; t[4] = p[4] - p[1]; t[5] = p[5] - p[2];
+                t[6] = p[6] - p[0]; t[7] = p[7] - p[1]; t[8] = p[8] - p[2];
+            } else {
+                p[0] = (float)s.a.x; p[1] = (float)s.a.y; p[2] = (float)s.a.z; p[3] = (float)s.b.x;
+                t[0] = p[0]; t[1] = p[1]; t[2] = p[2]; t[3] = p[3];
+            }
+            std::memcpy(&p[9], &bits, 4);
+            std::memcpy(&t[9], &bits, 4);
+        }
+    });
     std::vector<DMaterial> mats((size_t)desc->n_materials + 1);
     for (int64_t i = 0; i < desc->n_materials; ++i) {
         const rt_material& m = desc->materials[i];
