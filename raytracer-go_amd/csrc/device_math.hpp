@@ -400,6 +400,9 @@ RT_DEV uint32_t wave_scan_max(uint32_t x) {
 // (A first version dealt the queue out LEAF by leaf, at a time when the shape loop still ran after most
 // block visits: utilisation 0.20 -> 0.43 but frame 1.31 s -> 1.65 s, branch exp/balanced-shape-loop.  The
 // form below deals out single shapes and runs 2.3 times per 10 block visits.)
+// SAME_TMIN: tmin is the same for every lane of the wavefront (k_shadow's constant), so a lane that tests
+// another lane's shape need not fetch it with the rest of that lane's ray.
+template <bool SAME_TMIN>
 RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 d, float tmin, float tmax) {
     // Called by ALL 64 lanes of a wavefront (live = this lane has a ray).  The lanes walk their own rays, but
     // the shape loop is shared: the queued shapes of all lanes are dealt out evenly, one shape per lane and
@@ -447,9 +450,10 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
             const f3 oo = mk3(__shfl(o.x, owner), __shfl(o.y, owner), __shfl(o.z, owner));
             const f3 dd = mk3(__shfl(d.x, owner), __shfl(d.y, owner), __shfl(d.z, owner));
             const float tmx = __shfl(tmax, owner);
+            const float tmn = SAME_TMIN ? tmin : __shfl(tmin, owner);
             if (has && flag[owner] == 0u) {
                 RT_PROF_POINT(1);  // shape tests
-                const float t = prim_hit<true>(S, shape, oo, dd, tmin, tmx);
+                const float t = prim_hit<true>(S, shape, oo, dd, tmn, tmx);
                 if (t > 0.0f && t <= tmx) flag[owner] = 1u;
             }
         }

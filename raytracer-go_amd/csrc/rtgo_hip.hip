@@ -407,7 +407,7 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
             }
             RT_PROF_POINT(2);  // shadow-ray rounds
             // all 64 lanes call: lanes without a ray of their own test shapes for the others
-            const bool occ = occluded(S, st, traced, p, dir, 0.01f, dist);
+            const bool occ = occluded<true>(S, st, traced, p, dir, 0.01f, dist);
             vis = traced && !occ;
             const unsigned long long m = __ballot(vis);
             count += (uint32_t)__popcll(m & gmask);
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_probe(DScene S, Work Wk, const
         const bool live = i < n;
         const float* q = rays + (size_t)(live ? i : 0u) * 8;
         if (any_hit) {
-            const bool occ = occluded(S, st, live, mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), q[6], q[7]);
+            const bool occ = occluded<false>(S, st, live, mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), q[6], q[7]);
             if (live) { prim_out[i] = occ ? 1 : 0; t_out[i] = 0.0f; }
         } else if (live) {
             float t; int prim;
