@@ -503,3 +503,26 @@ def test_large_mesh_properties(backend, bridge, rt, scenes):
         r[:, 7] = t * (1 - 1e-3)
         occ, _ = dev.trace_rays(r, any_hit=True)
         assert not occ.any()
+
+
+def test_incoherent_rays_with_per_ray_intervals(backend, bridge, rt, scenes):
+    """rt_trace_rays on rays that share nothing: random origins and directions and a [tMin, tMax] of their own
+    each (the shadow rays of a frame all have tMin = 0.01).  Nearest hit and any hit bit-exact against the
+    oracle's fp32 mirror; the shape loop shared by a wavefront must test every shape with its owner's
+    interval."""
+    _, scene = scenes.config3(64, 36, 1, 1, nu=200, nv=200)
+    rng = np.random.default_rng(44)
+    n = 60000 + 37  # not a multiple of the wavefront
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0] = rng.uniform(-5, 5, n); rays[:, 1] = rng.uniform(0.2, 6, n); rays[:, 2] = rng.uniform(-5, 5, n)
+    d = rng.normal(size=(n, 3))
+    rays[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 6] = rng.uniform(0, 6, n) * (rng.random(n) < 0.7)
+    rays[:, 7] = rays[:, 6] + rng.exponential(3.0, n)
+    with backend.DeviceScene(scene) as dev, bridge.OracleScene(scene) as osc:
+        gp, gt = dev.trace_rays(rays)
+        op, ot = osc.trace_rays(rays.astype(np.float64), mode=bridge.F32_STACK)
+        assert np.array_equal(gp, op) and np.array_equal(gt[gp >= 0], ot.astype(np.float32)[gp >= 0])
+        go, _ = dev.trace_rays(rays, any_hit=True)
+        oo, _ = osc.trace_rays(rays.astype(np.float64), mode=bridge.F32_STACK, any_hit=True)
+        assert np.array_equal(go != 0, oo != 0) and 0.1 < (go != 0).mean() < 0.9
