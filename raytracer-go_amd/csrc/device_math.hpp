@@ -200,7 +200,7 @@ __device__ unsigned long long g_prof2[4];  // shadow-ray flushes: shapes queued 
 #endif
 constexpr int kLdsStackDepth = RTGO_LDS_STACK;
 #ifndef RTGO_PEND_CAP
-#define RTGO_PEND_CAP 16
+#define RTGO_PEND_CAP 8
 #endif
 #ifndef RTGO_FLUSH_LANES
 #define RTGO_FLUSH_LANES 64
@@ -242,35 +242,38 @@ RT_DEV void visit_block(const DScene& S, uint32_t cur, const TraceRay& r, float 
     // latency per block instead of one per child.  A slot's record is first + (present slots below it);
     // for an absent slot that is the record of the next present slot, or the record after the block's
     // last (the array is padded by one), fetched and then masked out.
-    float4 ra[8], rb[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint32_t oct = (uint32_t)k ^ r.sign;
-        const size_t idx = (size_t)first + (uint32_t)__popc(present & ((1u << oct) - 1u));
-        ra[k] = S.recs[2 * idx];
-        rb[k] = S.recs[2 * idx + 1];
-    }
-    // leaf mask of this block in octant order (every record of a block carries it; the first is always there)
     const uint32_t leaves = __float_as_uint(S.recs[2 * (size_t)first + 1].w);
     uint32_t hit = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {  // no branch per slot: an absent slot's result is masked out below
-        const float4 a = ra[k], b = rb[k];
-        float tn = t_enter, tf = entry_best;
-        {
-            const float lo = fmaf(a.x, r.inv.x, -r.oi.x), hi = fmaf(a.w, r.inv.x, -r.oi.x);
-            tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+    for (int h = 0; h < 8; h += 4) {  // two batches of four records: half the registers in flight
+        float4 ra[4], rb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t oct = (uint32_t)(h + k) ^ r.sign;
+            const size_t idx = (size_t)first + (uint32_t)__popc(present & ((1u << oct) - 1u));
+            ra[k] = S.recs[2 * idx];
+            rb[k] = S.recs[2 * idx + 1];
         }
-        {
-            const float lo = fmaf(a.y, r.inv.y, -r.oi.y), hi = fmaf(b.x, r.inv.y, -r.oi.y);
-            tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 a = ra[k], b = rb[k];
+            float tn = t_enter, tf = entry_best;
+            {
+                const float lo = fmaf(a.x, r.inv.x, -r.oi.x), hi = fmaf(a.w, r.inv.x, -r.oi.x);
+                tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+            }
+            {
+                const float lo = fmaf(a.y, r.inv.y, -r.oi.y), hi = fmaf(b.x, r.inv.y, -r.oi.y);
+                tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+            }
+            {
+                const float lo = fmaf(a.z, r.inv.z, -r.oi.z), hi = fmaf(b.y, r.inv.z, -r.oi.z);
+                tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
+            }
+            hit |= tn <= tf ? (1u << (h + k)) : 0u;
+            ref[h + k] = __float_as_uint(b.z);
         }
-        {
-            const float lo = fmaf(a.z, r.inv.z, -r.oi.z), hi = fmaf(b.y, r.inv.z, -r.oi.z);
-            tn = fmaxf(tn, fminf(lo, hi)); tf = fminf(tf, fmaxf(lo, hi));
-        }
-        hit |= tn <= tf ? (1u << k) : 0u;
-        ref[k] = __float_as_uint(b.z);
+        asm volatile("" ::: "memory");
     }
     // present and leaf masks are in octant order; ray-order position k holds octant k ^ sign, and that
     // permutation of the bits is three conditional swaps (halves, pairs, neighbours) of both masks at once

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_compact(Work Wk, uint32_t n_hit
 // a power of two <= 64; each lane runs repetitions r, r+group, ...  The visible repetitions of a
 // (hit, light) are counted with a ballot popcount: integer, so the result has no summation order.
 #ifndef RTGO_SHADOW_WAVES
-#define RTGO_SHADOW_WAVES 4
+#define RTGO_SHADOW_WAVES 5
 #endif
 __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, Batch B, Work Wk, uint32_t n_hits, int bounce,
                                                    int group, int group_shift, const uint32_t* pair_counter) {
