@@ -205,6 +205,10 @@ constexpr int kLdsStackDepth = RTGO_LDS_STACK;
 #ifndef RTGO_FLUSH_LANES
 #define RTGO_FLUSH_LANES 64
 #endif
+#ifndef RTGO_VISIT_BATCH
+#define RTGO_VISIT_BATCH 4
+#endif
+constexpr int kVisitBatch = RTGO_VISIT_BATCH;  // child records fetched together in a block visit (8, 4 or 2)
 constexpr int kPendCap = RTGO_PEND_CAP;        // leaves a lane can hold back (one block visit adds at most 8)
 constexpr int kFlushLanes = RTGO_FLUSH_LANES;  // run the shape loop when this many lanes hold leaves
 constexpr int kLdsPerLane = kLdsStackDepth + kPendCap + 1;  // +1: the branch-free append stores one past the last
@@ -245,17 +249,17 @@ RT_DEV void visit_block(const DScene& S, uint32_t cur, const TraceRay& r, float 
     const uint32_t leaves = __float_as_uint(S.recs[2 * (size_t)first + 1].w);
     uint32_t hit = 0;
 #pragma unroll
-    for (int h = 0; h < 8; h += 4) {  // two batches of four records: half the registers in flight
-        float4 ra[4], rb[4];
+    for (int h = 0; h < 8; h += kVisitBatch) {  // batches of kVisitBatch records: fewer registers in flight
+        float4 ra[kVisitBatch], rb[kVisitBatch];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kVisitBatch; ++k) {
             const uint32_t oct = (uint32_t)(h + k) ^ r.sign;
             const size_t idx = (size_t)first + (uint32_t)__popc(present & ((1u << oct) - 1u));
             ra[k] = S.recs[2 * idx];
             rb[k] = S.recs[2 * idx + 1];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kVisitBatch; ++k) {
             const float4 a = ra[k], b = rb[k];
             float tn = t_enter, tf = entry_best;
             {
