@@ -203,14 +203,15 @@ constexpr int kLdsStackDepth = RTGO_LDS_STACK;
 #define RTGO_PEND_CAP 8
 #endif
 #ifndef RTGO_FLUSH_LANES
-#define RTGO_FLUSH_LANES 64
+#define RTGO_FLUSH_LANES 16
 #endif
 #ifndef RTGO_VISIT_BATCH
 #define RTGO_VISIT_BATCH 4
 #endif
 constexpr int kVisitBatch = RTGO_VISIT_BATCH;  // child records fetched together in a block visit (8, 4 or 2)
 constexpr int kPendCap = RTGO_PEND_CAP;        // leaves a lane can hold back (one block visit adds at most 8)
-constexpr int kFlushLanes = RTGO_FLUSH_LANES;  // run the shape loop when this many lanes hold leaves
+constexpr int kFlushLanes = RTGO_FLUSH_LANES;  // occluded(): run the shared shape loop when this many lanes hold leaves
+constexpr int kFlushLanesNearest = 64;         // traverse(): every lane loops over its own shapes, so wait for all
 constexpr int kLdsPerLane = kLdsStackDepth + kPendCap + 1;  // +1: the branch-free append stores one past the last
 struct TraceStack {
     uint32_t* lds;        // &s_stack[threadIdx.x], entries kBlock apart: [0, kLdsStackDepth) stack, then the leaf queue
@@ -368,7 +369,7 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
         if (walking) walking = next_block(st, ref, inner_mask, &cur, &sp);
         const int n_walking = __popcll(__ballot(walking));
         const int n_holding = __popcll(__ballot(npend > 0u));
-        if (n_holding > 0 && n_holding >= (n_walking < kFlushLanes ? n_walking : kFlushLanes)) flush();
+        if (n_holding > 0 && n_holding >= (n_walking < kFlushLanesNearest ? n_walking : kFlushLanesNearest)) flush();
         if (!walking && npend == 0u) break;
     }
     *t_out = best;
