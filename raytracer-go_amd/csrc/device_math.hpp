@@ -414,8 +414,8 @@ template <bool SAME_TMIN>
 RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 d, float tmin, float tmax) {
     // Called by ALL 64 lanes of a wavefront (live = this lane has a ray).  The lanes walk their own rays, but
     // the shape loop is shared: the queued shapes of all lanes are dealt out evenly, one shape per lane and
-    // round, whoever's ray it belongs to.  (Per flush the lanes hold 417 shapes on average, the fullest lane
-    // 16.4: 6.5 rounds instead of 16.4 iterations.)  The answer is an OR over the shapes: any order will do.
+    // round, whoever's ray it belongs to.  (Lane utilisation of the shape tests 0.91, against 0.38 when every
+    // lane looped over its own shapes.)  The answer is an OR over the shapes: any order will do.
     const TraceRay r = make_trace_ray(o, d);
     uint32_t cur = S.root_ref;
     int sp = 0;
