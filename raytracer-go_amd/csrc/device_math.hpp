@@ -430,11 +430,15 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
     own[lane] = 0u;
 
     auto flush = [&]() {
-        uint32_t mine = 0;
-        for (uint32_t q = 0; q < npend; ++q) mine += pend[q * st.lds_stride] & 0xffu;
+        uint32_t mine = 0;  // all entries are read at once (those past npend are stale and masked): one LDS latency
+#pragma unroll
+        for (uint32_t q = 0; q < (uint32_t)kPendCap; ++q) {
+            const uint32_t e = pend[q * st.lds_stride];
+            mine += q < npend ? (e & 0xffu) : 0u;
+        }
         const uint32_t sum = wave_scan_add(mine);  // this lane's shapes are items [sum - mine, sum) of the wavefront
         const uint32_t excl = sum - mine;
-        const uint32_t total = (uint32_t)__shfl((int)sum, 63);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)sum, 63);  // wave-uniform: the round loop is scalar
         flag[lane] = 0u;
         for (uint32_t base = 0; base < total; base += 64u) {
             // every lane whose items reach into this round marks where they begin; the owner of an item is the
