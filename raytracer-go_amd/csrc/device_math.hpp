@@ -451,21 +451,21 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
             const uint32_t item = base + (uint32_t)lane;
             const bool has = item < total;
             const int owner = (int)(wave_scan_max(own[lane]) & 63u);
-            uint32_t g = item - (uint32_t)__shfl((int)excl, owner);  // which of the owner's shapes
+            // everything that depends on the owner alone is fetched together, for lanes without an item too (their
+            // owner is a valid lane): one LDS latency instead of four in a row
             const uint32_t* const oq = pend + (owner - lane);          // the owner's queue
-            uint32_t shape = 0;
-            if (has) {
-                uint32_t leaf = oq[0];
-                for (uint32_t q = 1; g >= (leaf & 0xffu); ++q) { g -= leaf & 0xffu; leaf = oq[q * st.lds_stride]; }
-                shape = (leaf >> 8) + g;
-            }
+            const uint32_t first_excl = (uint32_t)__shfl((int)excl, owner);
+            uint32_t leaf = oq[0];
+            const uint32_t decided = flag[owner];
             const f3 oo = mk3(__shfl(o.x, owner), __shfl(o.y, owner), __shfl(o.z, owner));
             const f3 dd = mk3(__shfl(d.x, owner), __shfl(d.y, owner), __shfl(d.z, owner));
             const float tmx = __shfl(tmax, owner);
             const float tmn = SAME_TMIN ? tmin : __shfl(tmin, owner);
-            if (has && flag[owner] == 0u) {
+            if (has && decided == 0u) {
+                uint32_t g = item - first_excl;  // which of the owner's shapes
+                for (uint32_t q = 1; g >= (leaf & 0xffu); ++q) { g -= leaf & 0xffu; leaf = oq[q * st.lds_stride]; }
                 RT_PROF_POINT(1);  // shape tests
-                const float t = prim_hit<true>(S, shape, oo, dd, tmn, tmx);
+                const float t = prim_hit<true>(S, (leaf >> 8) + g, oo, dd, tmn, tmx);
                 if (t > 0.0f && t <= tmx) flag[owner] = 1u;
             }
         }
