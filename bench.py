@@ -149,7 +149,7 @@ def main():
                     issue = {"valu_insts_per_ray": isu["valu_insts_per_frame"] / (n_shadow / args.steps),
                              "valu_active_lane_frac": isu["valu_active_lane_frac"],
                              "valu_busy_frac_profiled": isu["valu_busy_seconds_per_frame"] / (shadow_s / args.steps),
-                             "source": "profiles/r01/l_final_pmc.txt"}
+                             "source": "profiles/r01/m_final_pmc.txt"}
         out = {
             "metric": "Mrays/s (whole node), Stanford Dragon 1080p 64spp",
             "value": rays / elapsed / 1e6,
