@@ -15,6 +15,8 @@
  *     library narrows to fp32 at upload (the device path computes in fp32).
  *   - All input pointers are borrowed for the duration of the call only.
  *   - Return 0 = RT_OK; negative = error, text via rt_last_error() (thread-local).
+ *   - No C++ exception leaves the library: host allocation failures come back as RT_ERR_LIMIT
+ *     ("out of host memory"), other host runtime errors as RT_ERR_DEVICE.
  *   - An rt_scene owns its device workspace: one call at a time per scene (different scenes,
  *     e.g. one per device, may be used from different threads concurrently).
  *   - Shape index (position in rt_scene_desc.shapes) is the primitive ID that

@@ -19,6 +19,8 @@
 #include <thread>
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -648,6 +650,21 @@ static void host_chunks(int64_t n, F&& f) {
     for (auto& t : th) t.join();
 }
 
+// The public entry points: no C++ exception crosses the C boundary (the reference panics; here the caller
+// gets an error code and rt_last_error()).
+template <class F>
+static int guarded(F&& f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(RT_ERR_LIMIT, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_DEVICE, std::string("host runtime error: ") + e.what());
+    } catch (...) {
+        return fail(RT_ERR_DEVICE, "unknown host runtime error");
+    }
+}
+
 extern "C" {
 
 const char* rt_last_error(void) { return g_err.c_str(); }
@@ -665,7 +682,7 @@ int rt_init(int device) {
     return RT_OK;
 }
 
-int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
+static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene** out) {
     if (!desc || !out) return fail(RT_ERR_INVALID, "desc/out is NULL");
     *out = nullptr;
     if (desc->n_shapes < 0 || desc->n_materials < 0 || desc->n_textures < 0 || desc->n_lights < 0)
@@ -754,10 +771,14 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     }
 
     rt_scene* s = new rt_scene();
+    struct Guard {  // an exception (std::bad_alloc in a table, std::system_error from a thread) must not leak the device buffers
+        rt_scene* s;
+        ~Guard() { if (s) rt_scene_destroy(s); }
+    } guard{s};
     s->device = device;
     s->from = desc->camera_look_from; s->at = desc->camera_look_at; s->up = desc->camera_up;
     s->aperture = desc->camera_aperture; s->fov = desc->camera_fov_deg;
-    auto bail = [&](int code) { rt_scene_destroy(s); return code; };
+    auto bail = [&](int code) { return code; };  // the guard releases the scene
 #define HIP_TRY_S(expr)                                                                          \
     do {                                                                                         \
         hipError_t e_ = (expr);                                                                  \
@@ -838,6 +859,7 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
     s->info.device_bytes = (int64_t)(rec_bytes + prims.size() * 4 + tprims.size() * 4 + mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
                                      lights.size() * sizeof(DLight)) + tex_bytes;  // + the spill region, see ensure_overflow()
     s->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    guard.s = nullptr;
     *out = s;
     return RT_OK;
 #undef HIP_TRY_S
@@ -862,7 +884,7 @@ int rt_scene_get_info(const rt_scene* s, rt_scene_info* out) {
     return RT_OK;
 }
 
-int rt_render_accum_device(rt_scene* s, const rt_image_spec* spec, const rt_partition* part_in,
+static int rt_render_accum_device_impl(rt_scene* s, const rt_image_spec* spec, const rt_partition* part_in,
                            float* d_accum, void* hip_stream, rt_stats* stats) {
     if (!s || !d_accum) return fail(RT_ERR_INVALID, "scene/accum is NULL");
     int rc = validate_spec(spec);
@@ -1010,7 +1032,7 @@ int rt_render_accum_device(rt_scene* s, const rt_image_spec* spec, const rt_part
     return RT_OK;
 }
 
-int rt_resolve_device(const float* d_accum, int32_t width, int32_t height, int32_t spp, uint8_t* d_rgba, void* hip_stream) {
+static int rt_resolve_device_impl(const float* d_accum, int32_t width, int32_t height, int32_t spp, uint8_t* d_rgba, void* hip_stream) {
     if (!d_accum || !d_rgba || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "bad resolve arguments");
     const int n = width * height;
     // AntiAliasingFactor 0: the reference scales by 1/0 = +Inf and 0 * Inf = NaN -> uint8(NaN); we emit 0
@@ -1020,7 +1042,7 @@ int rt_resolve_device(const float* d_accum, int32_t width, int32_t height, int32
     return RT_OK;
 }
 
-int rt_render_accum(rt_scene* s, const rt_image_spec* spec, const rt_partition* part, float* accum_out, rt_stats* stats) {
+static int rt_render_accum_impl(rt_scene* s, const rt_image_spec* spec, const rt_partition* part, float* accum_out, rt_stats* stats) {
     if (!s || !accum_out) return fail(RT_ERR_INVALID, "scene/accum is NULL");
     int rc = validate_spec(spec);
     if (rc != RT_OK) return rc;
@@ -1038,7 +1060,7 @@ int rt_render_accum(rt_scene* s, const rt_image_spec* spec, const rt_partition* 
     return rc;
 }
 
-int rt_render(rt_scene* s, const rt_image_spec* spec, const rt_partition* part, uint8_t* rgba_out, rt_stats* stats) {
+static int rt_render_impl(rt_scene* s, const rt_image_spec* spec, const rt_partition* part, uint8_t* rgba_out, rt_stats* stats) {
     if (!s || !rgba_out) return fail(RT_ERR_INVALID, "scene/rgba_out is NULL");
     int rc = validate_spec(spec);
     if (rc != RT_OK) return rc;
@@ -1061,7 +1083,7 @@ int rt_render(rt_scene* s, const rt_image_spec* spec, const rt_partition* part, 
     return rc;
 }
 
-int rt_generate_image(const rt_scene_desc* desc, const rt_image_spec* spec, const rt_partition* part, uint8_t* rgba_out, rt_stats* stats) {
+static int rt_generate_image_impl(const rt_scene_desc* desc, const rt_image_spec* spec, const rt_partition* part, uint8_t* rgba_out, rt_stats* stats) {
     int rc = validate_spec(spec);
     if (rc != RT_OK) return rc;
     rt_scene* s = nullptr;
@@ -1072,7 +1094,7 @@ int rt_generate_image(const rt_scene_desc* desc, const rt_image_spec* spec, cons
     return rc;
 }
 
-int rt_trace_rays(rt_scene* s, const float* rays, int64_t n, int32_t any_hit, int32_t* prim_out, float* t_out) {
+static int rt_trace_rays_impl(rt_scene* s, const float* rays, int64_t n, int32_t any_hit, int32_t* prim_out, float* t_out) {
     if (!s || !rays || !prim_out || !t_out || n < 0) return fail(RT_ERR_INVALID, "bad trace arguments");
     if (n == 0) return RT_OK;
     if (n > ((int64_t)1 << 30)) return fail(RT_ERR_LIMIT, "more than 2^30 rays in one call");
@@ -1095,7 +1117,7 @@ int rt_trace_rays(rt_scene* s, const float* rays, int64_t n, int32_t any_hit, in
     return RT_OK;
 }
 
-int rt_camera_rays(rt_scene* s, const rt_image_spec* spec, uint64_t seed, const int32_t* pixels, int64_t n, float* rays_out) {
+static int rt_camera_rays_impl(rt_scene* s, const rt_image_spec* spec, uint64_t seed, const int32_t* pixels, int64_t n, float* rays_out) {
     if (!s || !pixels || !rays_out || n < 0) return fail(RT_ERR_INVALID, "bad camera arguments");
     int rc = validate_spec(spec);
     if (rc != RT_OK) return rc;
@@ -1129,5 +1151,31 @@ int rt_debug_prof(unsigned long long* out8, int reset) {
     return RT_OK;
 }
 #endif
+
+// The public entry points (guarded(), above: no C++ exception crosses the C boundary).
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
+    return guarded([&] { return rt_scene_create_impl(desc, device, out); });
+}
+int rt_render_accum_device(rt_scene* s, const rt_image_spec* spec, const rt_partition* part_in, float* d_accum, void* hip_stream, rt_stats* stats) {
+    return guarded([&] { return rt_render_accum_device_impl(s, spec, part_in, d_accum, hip_stream, stats); });
+}
+int rt_resolve_device(const float* d_accum, int32_t width, int32_t height, int32_t spp, uint8_t* d_rgba, void* hip_stream) {
+    return guarded([&] { return rt_resolve_device_impl(d_accum, width, height, spp, d_rgba, hip_stream); });
+}
+int rt_render_accum(rt_scene* s, const rt_image_spec* spec, const rt_partition* part, float* accum_out, rt_stats* stats) {
+    return guarded([&] { return rt_render_accum_impl(s, spec, part, accum_out, stats); });
+}
+int rt_render(rt_scene* s, const rt_image_spec* spec, const rt_partition* part, uint8_t* rgba_out, rt_stats* stats) {
+    return guarded([&] { return rt_render_impl(s, spec, part, rgba_out, stats); });
+}
+int rt_generate_image(const rt_scene_desc* desc, const rt_image_spec* spec, const rt_partition* part, uint8_t* rgba_out, rt_stats* stats) {
+    return guarded([&] { return rt_generate_image_impl(desc, spec, part, rgba_out, stats); });
+}
+int rt_trace_rays(rt_scene* s, const float* rays, int64_t n, int32_t any_hit, int32_t* prim_out, float* t_out) {
+    return guarded([&] { return rt_trace_rays_impl(s, rays, n, any_hit, prim_out, t_out); });
+}
+int rt_camera_rays(rt_scene* s, const rt_image_spec* spec, uint64_t seed, const int32_t* pixels, int64_t n, float* rays_out) {
+    return guarded([&] { return rt_camera_rays_impl(s, spec, seed, pixels, n, rays_out); });
+}
 
 }  // extern "C"
