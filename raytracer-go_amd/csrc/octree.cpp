@@ -207,11 +207,11 @@ struct SahBuilder {
     static void chunks(int32_t b, int32_t e, int nt, F&& f) {
         if (nt <= 1) { f(0, b, e); return; }
         const int64_t len = e - b;
-        std::vector<std::thread> th;
+        ThreadGroup group;
         for (int c = 1; c < nt; ++c)
-            th.emplace_back([&f, b, len, nt, c] { f(c, b + (int32_t)(len * c / nt), b + (int32_t)(len * (c + 1) / nt)); });
+            group.run([&f, b, len, nt, c] { f(c, b + (int32_t)(len * c / nt), b + (int32_t)(len * (c + 1) / nt)); });
         f(0, b, b + (int32_t)(len / nt));
-        for (auto& t : th) t.join();
+        group.join();
     }
     int32_t build(int32_t b, int32_t e, int depth, int threads) {
         // a long range is swept by all the threads this subtree may use; min, max and counts merge exactly,
@@ -342,7 +342,8 @@ struct SahBuilder {
         if (threads > 1 && mid - b >= kParallelMin && e - mid >= kParallelMin) {
             int tl = (int)(((int64_t)threads * (mid - b) + (e - b) / 2) / (e - b));
             tl = tl < 1 ? 1 : (tl > threads - 1 ? threads - 1 : tl);
-            std::thread left([&] { l = build(b, mid, depth + 1, tl); });
+            ThreadGroup left;
+            left.run([&] { l = build(b, mid, depth + 1, tl); });
             r = build(mid, e, depth + 1, threads - tl);
             left.join();
         } else {  // a short half is not worth a thread: the long one keeps them all
@@ -416,10 +417,10 @@ struct SahBuilder {
         auto work = [&] {
             for (size_t i = next.fetch_add(1); i < later.size(); i = next.fetch_add(1)) widen(later[i], 0, nullptr);
         };
-        std::vector<std::thread> th;
-        for (int c = 1; c < threads; ++c) th.emplace_back(work);
+        ThreadGroup group;
+        for (int c = 1; c < threads; ++c) group.run(work);
         work();
-        for (auto& t : th) t.join();
+        group.join();
     }
     // wide node for Bvh2 node `n` written into HostNode `at` (sequential: the order fixes the node numbers)
     void emit(std::vector<HostNode>& out, int32_t n, int32_t at) {

@@ -21,6 +21,10 @@
 //     every record's w1 also holds, in its low 8 bits, the leaf mask of the block it is in (octant order).
 #pragma once
 #include <cstdint>
+#include <exception>
+#include <mutex>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/rtgo.h"
@@ -30,6 +34,38 @@ namespace rtgo {
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr int64_t kMaxChildRecords = (int64_t)1 << 24;  // w0 keeps 24 bits for the block / shape index
 constexpr int kMaxLeafSize = 255;
+
+// A few host threads that are always joined, and whose first exception (std::bad_alloc, std::system_error)
+// is thrown again by join() on the thread that started them, instead of ending the process.
+class ThreadGroup {
+public:
+    template <class F>
+    void run(F f) {
+        threads_.emplace_back([this, f]() mutable {
+            try {
+                f();
+            } catch (...) {
+                std::lock_guard<std::mutex> g(m_);
+                if (!err_) err_ = std::current_exception();
+            }
+        });
+    }
+    void join() {
+        for (auto& t : threads_)
+            if (t.joinable()) t.join();
+        threads_.clear();
+        if (err_) std::rethrow_exception(std::exchange(err_, nullptr));
+    }
+    ~ThreadGroup() {
+        for (auto& t : threads_)
+            if (t.joinable()) t.join();
+    }
+
+private:
+    std::vector<std::thread> threads_;
+    std::exception_ptr err_;
+    std::mutex m_;
+};
 
 struct HostNode {
     double lo[3], hi[3];  // cell bounds while inserting, tight bounds after refit()

@@ -644,10 +644,10 @@ static void host_chunks(int64_t n, F&& f) {
     int nt = (int)std::thread::hardware_concurrency();
     nt = nt > 8 ? 8 : (nt < 1 ? 1 : nt);
     if (n < 65536) nt = 1;
-    std::vector<std::thread> th;
-    for (int c = 1; c < nt; ++c) th.emplace_back([&f, n, nt, c] { f(n * c / nt, n * (c + 1) / nt); });
+    ThreadGroup group;
+    for (int c = 1; c < nt; ++c) group.run([&f, n, nt, c] { f(n * c / nt, n * (c + 1) / nt); });
     f(0, n / nt);
-    for (auto& t : th) t.join();
+    group.join();
 }
 
 // The public entry points: no C++ exception crosses the C boundary (the reference panics; here the caller

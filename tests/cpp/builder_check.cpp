@@ -12,7 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <random>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "../../raytracer-go_amd/csrc/octree.hpp"
@@ -132,6 +135,22 @@ int main() {
         }
         unsetenv("RTGO_BUILD_THREADS");
         check_scene("two clusters, threaded", v, 6);
+    }
+    {   // the builders' threads: an exception in a worker comes back on the starting thread, after every worker has ended
+        std::atomic<int> done{0};
+        bool thrown = false;
+        try {
+            ThreadGroup g;
+            for (int i = 0; i < 6; ++i)
+                g.run([&done, i] {
+                    if (i == 3) throw std::runtime_error("worker 3");
+                    ++done;
+                });
+            g.join();
+        } catch (const std::runtime_error& e) {
+            thrown = std::string(e.what()) == "worker 3";
+        }
+        CHECK(thrown && done.load() == 5, "ThreadGroup: thrown %d, workers done %d", (int)thrown, done.load());
     }
     std::printf(fails ? "%d FAILURES\n" : "all builder invariants hold\n", fails);
     return fails ? 1 : 0;
