@@ -172,7 +172,7 @@ RT_DEV float prim_hit(const DScene& S, uint32_t prim, f3 o, f3 d, float tmin, fl
 // ---- optional loop instrumentation (make prof -> librtgo_prof.so, scripts/prof_loops.py) ----
 #ifdef RTGO_PROF
 __device__ unsigned long long g_prof[8];
-__device__ unsigned long long g_prof2[4];  // shadow-ray flushes: shapes queued in total, largest per-lane count, lanes in the wavefront  // [2i] = times a wavefront passed point i, [2i+1] = lanes active there
+__device__ unsigned long long g_prof2[4];  // shadow-ray walk: iterations, lanes only holding leaves, idle lanes, shape loops  // [2i] = times a wavefront passed point i, [2i+1] = lanes active there
 #define RT_PROF_POINT(i)                                                          \
     do {                                                                          \
         const unsigned long long m_ = __ballot(true);                             \
@@ -430,6 +430,9 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
     own[lane] = 0u;
 
     auto flush = [&]() {
+#ifdef RTGO_PROF
+        if (lane == 0) atomicAdd(&g_prof2[3], 1ull);
+#endif
         uint32_t mine = 0;  // all entries are read at once (those past npend are stale and masked): one LDS latency
 #pragma unroll
         for (uint32_t q = 0; q < (uint32_t)kPendCap; ++q) {
@@ -479,6 +482,16 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
     for (;;) {
         uint32_t ref[8];
         uint32_t leaf_mask = 0, inner_mask = 0;
+#ifdef RTGO_PROF
+        {   // per iteration of the walk: lanes that only hold leaves, lanes with nothing to do
+            const unsigned long long hold = __ballot(!walking && npend > 0u), idle = __ballot(!walking && npend == 0u);
+            if (lane == 0) {
+                atomicAdd(&g_prof2[0], 1ull);
+                atomicAdd(&g_prof2[1], (unsigned long long)__popcll(hold));
+                atomicAdd(&g_prof2[2], (unsigned long long)__popcll(idle));
+            }
+        }
+#endif
         if (walking) visit_block(S, cur, r, tmin, tmax, ref, &leaf_mask, &inner_mask);  // a box that ends before tmin holds no accepted hit
         if (__ballot(npend + (uint32_t)__popc(leaf_mask) > (uint32_t)kPendCap) != 0ull) {
             flush();

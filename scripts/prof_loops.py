@@ -20,7 +20,7 @@ print("shadow rays", st.rays_shadow, "ms_shadow %.1f" % st.ms_shadow, "wave roun
 for name, i in (("block visits", 0), ("shape tests", 1)):
     print("%-12s: %.1f per wave round, %.1f per ray, lane utilisation %.2f" %
           (name, v[2 * i] / rounds, v[2 * i + 1] / st.rays_shadow, v[2 * i + 1] / (64.0 * v[2 * i])))
-fl = v[6]
-if fl:
-    print("shadow-ray shape loops: %.2f per wave round; per loop: %.1f lanes hold leaves (of %.1f in the wavefront), %.1f shapes in total, largest lane %.1f -> ideal %.1f iterations if dealt out evenly"
-          % (fl / rounds, v[7] / fl, v[10] / fl, v[8] / fl, v[9] / fl, v[8] / fl / 64.0))
+it = v[8]
+if it:
+    print("shadow-ray walk: %.1f iterations per wave round; per iteration %.1f lanes only hold leaves, %.1f lanes have nothing to do; %.2f shape loops per wave round"
+          % (it / rounds, v[9] / it, v[10] / it, v[11] / rounds))
