@@ -86,6 +86,7 @@ constexpr uint32_t kPrimSingleSided = 2u;
 
 struct DScene {
     const float4* recs;    // 2 float4 per child record: {min.xyz, max.x}, {max.y, max.z, w0, w1}
+    const uint4* qblocks;  // 5 uint4 per block: the same tree with quantised boxes (octree.hpp QBlock), shadow rays only
     const float4* prims;   // 3 float4 per shape, in LEAF order: tri {A, B.x}{B.yz, C.xy}{C.z, bits, -, -}; sphere {C, R}{-}{-, bits}
     const float4* tprims;  // the same for the intersection tests: edges e1 = B - A, e2 = C - A in place of B, C
     const int* prim_ids;   // leaf-order shape q -> position in Scene.Shapes
@@ -377,6 +378,116 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
     return best_prim >= 0;
 }
 
+// ---- the shadow-ray walk over quantised blocks ------------------------------------------------
+// k_shadow is bound by the vector-memory path (TA busy 77-90 %, about one L1 access per clock and CU,
+// profiles/r02): a visit of the exact blocks issues 17 loads of 16 bytes per lane.  A shadow ray only asks
+// "is anything hit", an OR over shapes, so its walk may use any boxes that ENCLOSE the children: here the 8
+// slots' boxes as bytes on a power-of-two grid anchored at the block's minimum corner (octree.hpp QBlock),
+// 5 loads per visit.  A box that is a little too large costs a visit, never a hit.
+struct QRay {
+    f3 inv, oi;      // 1 / d and o / d as in TraceRay
+    uint32_t sign;   // bit a: the SIGN BIT of d on axis a (so -0 counts as negative, like 1 / -0 = -inf)
+};
+RT_DEV QRay make_qray(f3 o, f3 d) {
+    QRay r;
+    r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    r.oi = mk3(o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z);
+    r.sign = (__float_as_uint(d.x) >> 31) | ((__float_as_uint(d.y) >> 31) << 1) | ((__float_as_uint(d.z) >> 31) << 2);
+    return r;
+}
+RT_DEV float qbyte(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); }  // v_cvt_f32_ubyteN
+// Slab tests of the 8 slots of block `blk` in SLOT order.  hit: bit per slot whose box the ray meets inside
+// [tmin, tmax]; h1 = {child base | leaf mask << 24, first leaf shape, meta bytes of slots 0..3, 4..7}.
+RT_DEV uint32_t visit_qblock(const DScene& S, uint32_t blk, const QRay& r, float tmin, float tmax, uint4* h1_out) {
+    RT_PROF_POINT(0);  // block visits
+    const uint4* q = S.qblocks + 5 * (size_t)blk;
+    const uint4 h0 = q[0], h1 = q[1], qa = q[2], qb = q[3], qc = q[4];
+    // t = ((origin + q * step) - o) / d = q * (step / d) + (origin / d - o / d)
+    const float sx = __uint_as_float((h0.w & 0xffu) << 23) * r.inv.x;
+    const float sy = __uint_as_float((h0.w & 0xff00u) << 15) * r.inv.y;
+    const float sz = __uint_as_float((h0.w & 0xff0000u) << 7) * r.inv.z;
+    const float bx = fmaf(__uint_as_float(h0.x), r.inv.x, -r.oi.x);
+    const float by = fmaf(__uint_as_float(h0.y), r.inv.y, -r.oi.y);
+    const float bz = fmaf(__uint_as_float(h0.z), r.inv.z, -r.oi.z);
+    // the plane the ray enters through is the lower one for a positive direction, the upper one for a negative
+    const bool nx = (r.sign & 1u) != 0u, ny = (r.sign & 2u) != 0u, nz = (r.sign & 4u) != 0u;
+    uint32_t near_[3][2], far_[3][2];
+    near_[0][0] = nx ? qb.z : qa.x; near_[0][1] = nx ? qb.w : qa.y; far_[0][0] = nx ? qa.x : qb.z; far_[0][1] = nx ? qa.y : qb.w;
+    near_[1][0] = ny ? qc.x : qa.z; near_[1][1] = ny ? qc.y : qa.w; far_[1][0] = ny ? qa.z : qc.x; far_[1][1] = ny ? qa.w : qc.y;
+    near_[2][0] = nz ? qc.z : qb.x; near_[2][1] = nz ? qc.w : qb.y; far_[2][0] = nz ? qb.x : qc.z; far_[2][1] = nz ? qb.y : qc.w;
+    uint32_t hit = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int w = k >> 2, b = k & 3;
+        // a NaN (0 * inf for a direction component of 0) drops out of fmaxf / fminf: that axis then culls nothing
+        const float tn = fmaxf(fmaxf(fmaf(qbyte(near_[0][w], b), sx, bx), fmaf(qbyte(near_[1][w], b), sy, by)),
+                               fmaxf(fmaf(qbyte(near_[2][w], b), sz, bz), tmin));
+        const float tf = fminf(fminf(fmaf(qbyte(far_[0][w], b), sx, bx), fmaf(qbyte(far_[1][w], b), sy, by)),
+                               fminf(fmaf(qbyte(far_[2][w], b), sz, bz), tmax));
+        hit |= tn <= tf ? (1u << k) : 0u;
+    }
+    *h1_out = h1;
+    return hit & (h0.w >> 24);
+}
+// slot-order mask -> ray-order mask: position k holds slot k ^ sign (three conditional swaps)
+RT_DEV uint32_t ray_order8(uint32_t m, uint32_t sign) {
+    const uint32_t s4 = sign & 4u, s2 = sign & 2u, s1 = sign & 1u;
+    m = ((m >> s4) & 0x0fu) | ((m << s4) & 0xf0u);
+    m = ((m >> s2) & 0x33u) | ((m << s2) & 0xccu);
+    m = ((m >> s1) & 0x55u) | ((m << s1) & 0xaau);
+    return m;
+}
+// Hit leaf children -> the lane's leaf queue as (first shape << 8 | count), in slot order (the order of a shadow
+// ray's shape tests is free).  The leaves' shapes are consecutive: first = base + counts of the leaves before it;
+// the low 5 bits of a meta byte are the shape count of a leaf and 0 for an inner or absent slot, so a byte-wise
+// running sum over the two meta words gives every slot's offset.  One iteration per hit leaf (0.4 per visit).
+RT_DEV void queue_qleaves(uint32_t* pend, uint32_t stride, const uint4& h1, uint32_t leaf_hits, uint32_t* npend) {
+    if (leaf_hits == 0u) return;
+    const uint32_t c_lo = h1.z & 0x1f1f1f1fu, c_hi = h1.w & 0x1f1f1f1fu;
+    uint32_t i_lo = c_lo + (c_lo << 8); i_lo += i_lo << 16;  // inclusive byte-wise sums (8 x 31 < 256: no carry)
+    uint32_t i_hi = c_hi + (c_hi << 8); i_hi += i_hi << 16;
+    const uint32_t p_lo = i_lo << 8;                                       // exclusive sums of slots 0..3
+    const uint32_t p_hi = (i_hi << 8) + (i_lo >> 24) * 0x01010101u;        // slots 4..7: + everything in slots 0..3
+    uint32_t n = *npend;
+    uint32_t m = leaf_hits;
+    while (m) {
+        const int k = __ffs((int)m) - 1;
+        m &= m - 1u;
+        const uint32_t sh = (uint32_t)(k & 3) * 8u;
+        const uint32_t first = h1.y + (((k < 4 ? p_lo : p_hi) >> sh) & 0xffu);
+        pend[n * stride] = (first << 8) | (((k < 4 ? c_lo : c_hi) >> sh) & 0x1fu);
+        ++n;
+    }
+    *npend = n;
+}
+// Hit inner children pushed far-to-near in RAY order, the nearest then popped (as next_block()).
+RT_DEV bool next_qblock(const TraceStack& st, const uint4& h1, uint32_t inner_hits, uint32_t sign, uint32_t* cur, int* sp_io) {
+    int sp = *sp_io;
+    if (inner_hits) {
+        const uint32_t m = ray_order8(inner_hits, sign);
+        const uint32_t base = h1.x & 0xffffffu;
+        // meta bytes brought to ray order: position i <- slot i ^ sign
+        const uint32_t sel = 0x03020100u ^ (sign * 0x01010101u);
+        const uint32_t mlo = __builtin_amdgcn_perm(h1.w, h1.z, sel), mhi = __builtin_amdgcn_perm(h1.w, h1.z, sel ^ 0x04040404u);
+        if (sp + 8 <= kLdsStackDepth) {
+#pragma unroll
+            for (int k = 7; k >= 0; --k) {
+                const uint32_t rank = ((k < 4 ? mlo : mhi) >> (8 * (k & 3) + 5)) & 7u;
+                st.lds[sp * st.lds_stride] = base + rank;
+                sp += (int)((m >> k) & 1u);
+            }
+        } else {
+#pragma unroll
+            for (int k = 7; k >= 0; --k)
+                if ((m >> k) & 1u) st.put(sp++, base + (((k < 4 ? mlo : mhi) >> (8 * (k & 3) + 5)) & 7u));
+        }
+    }
+    if (sp == 0) return false;
+    *cur = st.get(--sp);
+    *sp_io = sp;
+    return true;
+}
+
 // Inclusive scans over the 64 lanes of a wavefront through the DPP path (shifts within rows of 16 lanes,
 // then the last lane of a row broadcast to the rows after it); every lane of the wavefront must be active.
 template <int CTRL, int ROWS>
@@ -416,8 +527,8 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
     // the shape loop is shared: the queued shapes of all lanes are dealt out evenly, one shape per lane and
     // round, whoever's ray it belongs to.  (Lane utilisation of the shape tests 0.91, against 0.38 when every
     // lane looped over its own shapes.)  The answer is an OR over the shapes: any order will do.
-    const TraceRay r = make_trace_ray(o, d);
-    uint32_t cur = S.root_ref;
+    const QRay r = make_qray(o, d);
+    uint32_t cur = 0u;  // block index; the root is block 0
     int sp = 0;
     bool walking = live;
     bool occ = false;
@@ -480,7 +591,7 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
     };
 
     for (;;) {
-        uint32_t ref[8];
+        uint4 h1 = make_uint4(0u, 0u, 0u, 0u);
         uint32_t leaf_mask = 0, inner_mask = 0;
 #ifdef RTGO_PROF
         {   // per iteration of the walk: lanes that only hold leaves, lanes with nothing to do
@@ -492,13 +603,17 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
             }
         }
 #endif
-        if (walking) visit_block(S, cur, r, tmin, tmax, ref, &leaf_mask, &inner_mask);  // a box that ends before tmin holds no accepted hit
+        if (walking) {  // a box that ends before tmin holds no accepted hit
+            const uint32_t hit = visit_qblock(S, cur, r, tmin, tmax, &h1);
+            leaf_mask = hit & (h1.x >> 24);
+            inner_mask = hit & ~(h1.x >> 24);
+        }
         if (__ballot(npend + (uint32_t)__popc(leaf_mask) > (uint32_t)kPendCap) != 0ull) {
             flush();
             if (occ) leaf_mask = 0u;  // this lane's ray is decided: nothing more to queue
         }
-        queue_leaves(pend, st.lds_stride, ref, leaf_mask, &npend);
-        if (walking) walking = next_block(st, ref, inner_mask, &cur, &sp);
+        queue_qleaves(pend, st.lds_stride, h1, leaf_mask, &npend);
+        if (walking) walking = next_qblock(st, h1, inner_mask, r.sign, &cur, &sp);
         const int n_walking = __popcll(__ballot(walking));
         const int n_holding = __popcll(__ballot(npend > 0u));
         if (n_holding > 0 && n_holding >= (n_walking < kFlushLanes ? n_walking : kFlushLanes)) flush();

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <deque>
 #include <unordered_map>
 #include <atomic>
@@ -558,11 +559,65 @@ static void block_slots(const std::vector<HostNode>& nodes, int32_t x, int leaf_
     }
 }
 
+// The block whose child records are records[first, first + count) (slot order, absent slots omitted), as a QBlock.
+static void append_qblock(FlatTree* out, int64_t first, int count, uint32_t present, uint32_t leaf_mask, uint32_t child_base) {
+    uint32_t w[kQBlockWords] = {};
+    const ChildRecord* rec = out->records.data() + first;
+    float origin[3], top[3];
+    for (int a = 0; a < 3; ++a) {
+        origin[a] = rec[0].bmin[a]; top[a] = rec[0].bmax[a];
+        for (int k = 1; k < count; ++k) { origin[a] = std::min(origin[a], rec[k].bmin[a]); top[a] = std::max(top[a], rec[k].bmax[a]); }
+    }
+    uint32_t exps = 0;
+    double step[3];
+    for (int a = 0; a < 3; ++a) {
+        const double ext = (double)top[a] - (double)origin[a];
+        int e = 1;  // biased exponent of the grid step: the smallest with ceil(ext / step) <= 255
+        if (ext > 0) {
+            int x;
+            (void)std::frexp(ext / 255.0, &x);  // ext / 255 = m * 2^x, 0.5 <= m < 1: step 2^x is enough
+            e = std::max(1, std::min(254, x + 127));
+            while (e < 254 && std::ceil(ext / std::ldexp(1.0, e - 127)) > 255.0) ++e;
+        }
+        step[a] = std::ldexp(1.0, e - 127);
+        exps |= (uint32_t)e << (8 * a);
+    }
+    for (int a = 0; a < 3; ++a) std::memcpy(&w[a], &origin[a], 4);
+    w[3] = exps | (present << 24);
+    w[4] = child_base | (leaf_mask << 24);
+    uint8_t* meta = reinterpret_cast<uint8_t*>(&w[6]);
+    uint8_t* qlo = reinterpret_cast<uint8_t*>(&w[8]);
+    uint8_t* qhi = reinterpret_cast<uint8_t*>(&w[14]);
+    int k = 0, rank = 0;
+    bool have_leaf = false;
+    for (int o = 0; o < 8; ++o) {
+        if (!((present >> o) & 1u)) continue;
+        const ChildRecord& r = rec[k++];
+        if ((leaf_mask >> o) & 1u) {
+            if (!have_leaf) { w[5] = r.w0 >> 8; have_leaf = true; }
+            meta[o] = (uint8_t)(r.w0 & 0xffu);
+        } else {
+            meta[o] = (uint8_t)(rank++ << 5);
+        }
+        for (int a = 0; a < 3; ++a) {
+            const double lo = std::floor(((double)r.bmin[a] - (double)origin[a]) / step[a]);
+            const double hi = std::ceil(((double)r.bmax[a] - (double)origin[a]) / step[a]);
+            qlo[8 * a + o] = (uint8_t)std::max(0.0, std::min(255.0, lo));
+            qhi[8 * a + o] = (uint8_t)std::max(0.0, std::min(255.0, hi));
+        }
+    }
+    out->qblocks.insert(out->qblocks.end(), w, w + kQBlockWords);
+}
+
 bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree* out, const char** err) {
     out->records.clear();
+    out->qblocks.clear();
     out->order.clear();
     out->root_ref = 0; out->n_inner = 0; out->depth = 0; out->stack_bound = 1;
-    if (nodes.empty() || nodes[0].empty) return true;  // no shapes: present mask 0 => every ray misses
+    if (nodes.empty() || nodes[0].empty) {  // no shapes: present mask 0 => every ray misses
+        out->qblocks.assign(kQBlockWords, 0u);
+        return true;
+    }
     if (leaf_size < 1) leaf_size = 1;
     if (leaf_size > kMaxLeafSize) leaf_size = kMaxLeafSize;
 
@@ -591,9 +646,11 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
         out->records.push_back(r);
         out->root_ref = (0u << 8) | 1u;
         out->n_inner = 1; out->depth = 1; out->stack_bound = 8;
+        append_qblock(out, 0, 1, 1u, 1u, 0u);
         return true;
     }
     queue.push_back({root, -1, 1});
+    uint32_t n_pushed = 1;  // the i-th node pushed becomes block i (first in, first out)
     while (!queue.empty()) {
         const Pending p = queue.front();
         queue.pop_front();
@@ -601,7 +658,7 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
         const int64_t first = (int64_t)out->records.size();
         int32_t slot[8];
         block_slots(nodes, p.node, leaf_size, slot);
-        uint32_t present = 0, leaf_mask = 0;
+        uint32_t present = 0, leaf_mask = 0, child_base = 0;
         for (int o = 0; o < 8; ++o) {
             const int32_t e = slot[o];
             if (e < 0) continue;
@@ -613,10 +670,13 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
                 leaf_mask |= 1u << o;
             } else {
                 r.w0 = 0; r.w1 = 0;
+                if ((present & ~leaf_mask) == (1u << o)) child_base = n_pushed;  // first inner child of this block
+                ++n_pushed;
                 queue.push_back({e, (int64_t)out->records.size(), p.level + 1});
             }
             out->records.push_back(r);
         }
+        append_qblock(out, first, (int)(out->records.size() - (size_t)first), present, leaf_mask, child_base);
         (void)nd;
         for (size_t k = (size_t)first; k < out->records.size(); ++k) out->records[k].w1 |= leaf_mask;
         if ((int64_t)out->records.size() > kMaxChildRecords || (int64_t)out->order.size() >= kMaxChildRecords) {

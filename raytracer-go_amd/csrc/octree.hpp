@@ -19,6 +19,10 @@
 //   - inner child : w0 = (first record of its block << 8) | 8-bit octant-present mask, w1 = 0 (+ mask below)
 //     leaf child  : w0 = (first re-ordered shape << 8) | shape count, w1 = kLeafFlag;
 //     every record's w1 also holds, in its low 8 bits, the leaf mask of the block it is in (octant order).
+//   - the same blocks once more as 80-byte QUANTISED blocks (QBlock) for the shadow-ray walk, whose answer is an
+//     OR over shapes and so needs boxes that enclose, not boxes that are exact: one block = the 8 slots' boxes as
+//     8-bit offsets on a per-block power-of-two grid, 5 x 16 bytes fetched per visit instead of up to 16 x 16
+//     (k_shadow is bound by the vector-memory path, profiles/r02).
 #pragma once
 #include <cstdint>
 #include <exception>
@@ -33,7 +37,20 @@ namespace rtgo {
 
 constexpr uint32_t kLeafFlag = 0x80000000u;
 constexpr int64_t kMaxChildRecords = (int64_t)1 << 24;  // w0 keeps 24 bits for the block / shape index
-constexpr int kMaxLeafSize = 255;
+constexpr int kMaxLeafSize = 31;  // 8 leaves of a block: their shape counts and the running sums fit bytes of a QBlock
+
+// Block b of the flattened tree for the shadow-ray walk (device_math.hpp visit_qblock), 20 words:
+//   [0..2]  origin: the minimum corner of the block's box (fp32, exact minimum of the children's rounded boxes)
+//   [3]     biased fp32 exponents of the grid step per axis (bytes 0..2: x, y, z) | slot-present mask << 24
+//   [4]     index of the block of the first inner child (inner children's blocks are consecutive, slot order)
+//           | leaf mask << 24
+//   [5]     first shape of the first leaf child (the leaf children's shapes are consecutive, slot order)
+//   [6..7]  one byte per slot: leaf: shape count (1..31); inner child: (rank among the inner children) << 5; absent: 0
+//   [8..13] lower planes: 8 bytes (slots 0..7) per axis x, y, z: floor((bmin - origin) / step)
+//   [14..19] upper planes likewise: ceil((bmax - origin) / step) <= 255
+// so that origin + q * step encloses the child's fp32 box in exact arithmetic.
+constexpr int kQBlockWords = 20;
+constexpr int64_t kMaxBlocks = (int64_t)1 << 24;
 
 // A few host threads that are always joined, and whose first exception (std::bad_alloc, std::system_error)
 // is thrown again by join() on the thread that started them, instead of ending the process.
@@ -83,6 +100,7 @@ struct ChildRecord {  // 32 bytes, read by the kernels as two float4
 
 struct FlatTree {
     std::vector<ChildRecord> records;
+    std::vector<uint32_t> qblocks;  // kQBlockWords per block, block i of the breadth-first order (root = 0)
     std::vector<int32_t> order;  // re-ordered shape q -> index in Scene.Shapes
     uint32_t root_ref = 0;  // (first << 8) | present of the root block
     int64_t n_inner = 0;    // blocks

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(kBlock) void k_camera_probe(DCamera cam, int W, int
 struct rt_scene {
     int device = 0;
     DScene d{};
-    void* d_recs = nullptr; void* d_prims = nullptr; void* d_tprims = nullptr; void* d_prim_ids = nullptr; void* d_mats = nullptr; void* d_texs = nullptr; void* d_lights = nullptr;
+    void* d_recs = nullptr; void* d_qblocks = nullptr; void* d_prims = nullptr; void* d_tprims = nullptr; void* d_prim_ids = nullptr; void* d_mats = nullptr; void* d_texs = nullptr; void* d_lights = nullptr;
     std::vector<void*> d_tex_pixels;
     rt_scene_info info{};
     double ms_build = 0;
@@ -826,9 +826,12 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     }
 
     const size_t rec_bytes = (flat.records.size() + 1) * sizeof(ChildRecord);
+    if (flat.qblocks.empty()) return bail(fail(RT_ERR_DEVICE, "flattener produced no quantised blocks"));
     HIP_TRY_S(hipMalloc(&s->d_recs, rec_bytes));
     HIP_TRY_S(hipMemset(s->d_recs, 0, rec_bytes));  // the padding record is fetched (and masked out) for trailing absent slots
     if (!flat.records.empty()) HIP_TRY_S(hipMemcpy(s->d_recs, flat.records.data(), flat.records.size() * sizeof(ChildRecord), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_qblocks, flat.qblocks.size() * sizeof(uint32_t)));
+    HIP_TRY_S(hipMemcpy(s->d_qblocks, flat.qblocks.data(), flat.qblocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_prims, prims.size() * sizeof(float)));
     HIP_TRY_S(hipMemcpy(s->d_prims, prims.data(), prims.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_tprims, tprims.size() * sizeof(float)));
@@ -846,7 +849,7 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     const int spill = flat.stack_bound + 1 > kLdsStackDepth ? flat.stack_bound + 1 - kLdsStackDepth : 0;  // +1: the nearest child is pushed, then popped
     s->spill = spill;  // the region itself is sized by ensure_overflow() for the grids a call really launches
 
-    s->d.recs = (const float4*)s->d_recs; s->d.prims = (const float4*)s->d_prims; s->d.tprims = (const float4*)s->d_tprims; s->d.prim_ids = (const int*)s->d_prim_ids;
+    s->d.recs = (const float4*)s->d_recs; s->d.qblocks = (const uint4*)s->d_qblocks; s->d.prims = (const float4*)s->d_prims; s->d.tprims = (const float4*)s->d_tprims; s->d.prim_ids = (const int*)s->d_prim_ids;
     s->d.materials = (const DMaterial*)s->d_mats; s->d.textures = (const DTexture*)s->d_texs;
     s->d.lights = (const DLight*)s->d_lights;
     s->d.n_lights = (int)desc->n_lights; s->d.n_pos_lights = n_pos; s->d.root_ref = flat.root_ref;
@@ -856,7 +859,7 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     s->info.n_shapes = desc->n_shapes; s->info.n_inner_nodes = flat.n_inner;
     s->info.n_child_records = (int64_t)flat.records.size();
     s->info.tree_depth = flat.depth; s->info.stack_bound = flat.stack_bound;
-    s->info.device_bytes = (int64_t)(rec_bytes + prims.size() * 4 + tprims.size() * 4 + mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
+    s->info.device_bytes = (int64_t)(rec_bytes + flat.qblocks.size() * 4 + prims.size() * 4 + tprims.size() * 4 + mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
                                      lights.size() * sizeof(DLight)) + tex_bytes;  // + the spill region, see ensure_overflow()
     s->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     guard.s = nullptr;
@@ -871,7 +874,7 @@ void rt_scene_destroy(rt_scene* s) {
     free_work(s);
     if (s->wk.overflow) (void)hipFree(s->wk.overflow);
     if (s->h_counters) (void)hipHostFree(s->h_counters);
-    void* ptrs[] = {s->d_recs, s->d_prims, s->d_tprims, s->d_prim_ids, s->d_mats, s->d_texs, s->d_lights};
+    void* ptrs[] = {s->d_recs, s->d_qblocks, s->d_prims, s->d_tprims, s->d_prim_ids, s->d_mats, s->d_texs, s->d_lights};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : s->d_tex_pixels) (void)hipFree(p);
     if (s->ev_ok) for (auto& e : s->ev) (void)hipEventDestroy(e);

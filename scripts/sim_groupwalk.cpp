@@ -1,0 +1,325 @@
+// Design-time simulation (CPU, not part of the product or of the oracle's checks): how much tree walking
+// would a (hit, light) pair's soft-shadow repetitions share if the pair walked the device tree ONCE with a
+// conservative beam (interval arithmetic over the repetitions' directions) instead of once per repetition?
+// Built on the oracle's fp32 mirror of the device tree:  g++ -O2 -shared -fPIC scripts/sim_groupwalk.cpp
+// (includes oracle/rtgo_oracle.cpp as a translation unit); driven by scripts/sim_groupwalk.py.
+#include "../oracle/rtgo_oracle.cpp"
+#include <unordered_map>
+
+namespace {
+
+struct Beam {
+    float o[3];
+    float ilo[3], ihi[3];   // bounds of 1/d over the rays (valid when !straddle)
+    bool straddle[3];
+    float tmin, tmax;
+    int sign;
+};
+
+inline bool beam_box(const Beam& b, const float* bmin, const float* bmax) {
+    float tn = b.tmin, tf = b.tmax;
+    for (int a = 0; a < 3; ++a) {
+        if (b.straddle[a]) continue;  // directions of both signs on this axis: no bound from it
+        const float x0 = bmin[a] - b.o[a], x1 = bmax[a] - b.o[a];
+        const float c0 = x0 * b.ilo[a], c1 = x0 * b.ihi[a], c2 = x1 * b.ilo[a], c3 = x1 * b.ihi[a];
+        // per ray: entry = min(t(b0), t(b1)), exit = max(...); over the interval: lower bound of entry = the smaller
+        // of the two planes' minima ... conservative: entry_lo = min over rays of min(plane0, plane1)
+        const float p0lo = fminf(c0, c1), p0hi = fmaxf(c0, c1), p1lo = fminf(c2, c3), p1hi = fmaxf(c2, c3);
+        const float entry_lo = fminf(p0lo, p1lo);
+        const float exit_hi = fmaxf(p0hi, p1hi);
+        // tighter: entry of a ray is the min of its two plane values, so entry_lo = min(p0lo, p1lo) is exact for the
+        // hull; exit_hi likewise
+        tn = fmaxf(tn, entry_lo);
+        tf = fminf(tf, exit_hi);
+    }
+    return tn <= tf;
+}
+// tighter variant: for same-sign direction intervals the near plane is known per axis
+inline bool beam_box_tight(const Beam& b, const float* bmin, const float* bmax) {
+    float tn = b.tmin, tf = b.tmax;
+    for (int a = 0; a < 3; ++a) {
+        if (b.straddle[a]) {
+            continue;
+        }
+        const bool neg = (b.sign >> a) & 1;
+        const float xn = (neg ? bmax[a] : bmin[a]) - b.o[a];  // near plane offset
+        const float xf = (neg ? bmin[a] : bmax[a]) - b.o[a];  // far plane offset
+        // t = x * inv; inv in [ilo, ihi] (same sign as direction).  entry lower bound = min(xn*ilo, xn*ihi)
+        const float e = fminf(xn * b.ilo[a], xn * b.ihi[a]);
+        const float x = fmaxf(xf * b.ilo[a], xf * b.ihi[a]);
+        tn = fmaxf(tn, e);
+        tf = fminf(tf, x);
+    }
+    return tn <= tf;
+}
+
+struct SimOut {
+    double pairs, rays;
+    double base_inner, base_leaf;          // per-ray walk: block visits, shape tests (early exit)
+    double grp_visits, grp_touched;        // beam walk: block visits, beam-touched leaves per pair
+    double ray_leafbox, ray_leafpass, ray_shape;  // per ray: own-ray leaf box tests, those passed, shape tests
+    double wave_base_iters, wave_grp_visits, wave_grp_touched, waves;  // max over the 4 pairs of a wavefront
+    double occluded_rays, fully_lit_pairs, fully_dark_pairs, empty_walk_pairs;
+};
+
+}  // namespace
+
+extern "C" int sim_groupwalk(const orc_scene* s, const rt_image_spec* spec, uint64_t seed, int subn, int tight, SimOut* out, float* rec, int64_t rec_cap, int64_t* n_rec) {
+    int64_t nr = 0;
+    const Scene& sc = s->sc;
+    const int W = spec->width, H = spec->height, reps = spec->soft_shadow_monte_carlo_repetitions;
+    const CameraF64 c64 = new_camera(sc, W, H);
+    const Camera<float> cf = narrow_camera<float>(c64);
+    const Tables<float>& T = sc.t32;
+    SimOut o{};
+    Node* root = effective(sc.wide_root);
+    const int leaf_size = sc.leaf_size;
+    struct PairCost { double base_max, visits, touched; };
+    std::vector<std::vector<PairCost>> per_light(T.lights.size());
+    for (int row = 0; row < H; ++row)
+        for (int i = 0; i < W; ++i) {
+            const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(row * W + i), 0u};
+            const Ray<float> r = camera_ray(cf, W, H, i, H - 1 - row, key);
+            Hit<float> hit;
+            if (!trace_stack_f32(sc, r, 0.0f, FLT_MAX, false, hit, nullptr)) continue;
+            const Shape<float>& sh = T.shapes[hit.shape];
+            const Material<float>& m = T.materials[sh.material];
+            if (m.kind != RT_MAT_PHONGBLINN) continue;
+            int lpos = -1;
+            for (size_t li = 0; li < T.lights.size(); ++li) {
+                const Light<float>& L = T.lights[li];
+                if (L.kind == RT_LIGHT_AMBIENT) continue;
+                ++lpos;
+                const V3<float> l2p = sub(L.pos, hit.p);
+                const V3<float> ldir = unit(l2p);
+                const float inten = saturate(dot(hit.normal, ldir));
+                const V3<float> h = unit(add(ldir, r.d));
+                const float si = std::pow(saturate(dot(hit.normal, h)), m.param);
+                if (inten == 0.0f && (si == 0.0f || (m.spec.x == 0 && m.spec.y == 0 && m.spec.z == 0))) continue;
+                std::vector<Ray<float>> rays; std::vector<float> dist;
+                for (int k = 0; k < reps; ++k) {
+                    const V3<float> jit = scale(0.25f, random_in_unit_sphere<float>(key, 0, P_SHADOW, (uint32_t)(lpos * reps + k)));
+                    const V3<float> shifted = add(L.pos, jit);
+                    if (L.kind == RT_LIGHT_SPOT && !(dot(L.look_dir, unit(sub(hit.p, shifted))) >= L.cos_angle)) continue;
+                    const V3<float> ld = sub(shifted, hit.p);
+                    const float d = norm(ld);
+                    rays.push_back({hit.p, scale(1.0f / d, ld)});
+                    dist.push_back(d);
+                }
+                if (rays.empty()) continue;
+                o.pairs += 1; o.rays += (double)rays.size();
+                // baseline
+                double bmax = 0; int nocc = 0; double pair_inner = 0, pair_leaf = 0;
+                std::vector<char> base_occ(rays.size());
+                for (size_t k = 0; k < rays.size(); ++k) {
+                    TraceCounters tc; Hit<float> hh;
+                    const bool occ = trace_stack_f32(sc, rays[k], 0.01f, dist[k], true, hh, &tc);
+                    base_occ[k] = occ;
+                    o.base_inner += (double)tc.inner; o.base_leaf += (double)tc.leaf; pair_inner += (double)tc.inner; pair_leaf += (double)tc.leaf;
+                    bmax = std::max(bmax, (double)tc.inner);
+                    nocc += occ;
+                }
+                o.occluded_rays += nocc;
+                if (nocc == 0) o.fully_lit_pairs += 1;
+                if (nocc == (int)rays.size()) o.fully_dark_pairs += 1;
+                // beam walk(s): sub-beams of `sub` rays (0 = all)
+                double visits = 0, touched = 0;
+                const size_t step = subn > 0 ? (size_t)subn : rays.size();
+                std::vector<char> occ(rays.size(), 0);
+                for (size_t b0 = 0; b0 < rays.size(); b0 += step) {
+                    const size_t b1 = std::min(rays.size(), b0 + step);
+                    Beam B{};
+                    B.o[0] = hit.p.x; B.o[1] = hit.p.y; B.o[2] = hit.p.z;
+                    B.tmin = 0.01f; B.tmax = 0;
+                    float dlo[3] = {1e30f, 1e30f, 1e30f}, dhi[3] = {-1e30f, -1e30f, -1e30f};
+                    V3<float> mean{0, 0, 0};
+                    for (size_t k = b0; k < b1; ++k) {
+                        const float d[3] = {rays[k].d.x, rays[k].d.y, rays[k].d.z};
+                        for (int a = 0; a < 3; ++a) { dlo[a] = std::min(dlo[a], d[a]); dhi[a] = std::max(dhi[a], d[a]); }
+                        B.tmax = std::max(B.tmax, dist[k]);
+                        mean = add(mean, rays[k].d);
+                    }
+                    B.sign = (mean.x < 0 ? 1 : 0) | (mean.y < 0 ? 2 : 0) | (mean.z < 0 ? 4 : 0);
+                    for (int a = 0; a < 3; ++a) {
+                        B.straddle[a] = !(dlo[a] > 0.0f || dhi[a] < 0.0f);
+                        if (!B.straddle[a]) { B.ilo[a] = 1.0f / dhi[a]; B.ihi[a] = 1.0f / dlo[a]; }
+                    }
+                    std::vector<StackRay> srs;
+                    for (size_t k = b0; k < b1; ++k) srs.push_back(make_stack_ray(rays[k]));
+                    size_t undecided = b1 - b0;
+                    std::vector<Node*> stack;
+                    Node* cur = root;
+                    std::vector<int> group;
+                    if (root->count <= leaf_size) { cur = nullptr; }
+                    while (cur && undecided > 0) {
+                        visits += 1;
+                        Node* pending[8]; int np = 0;
+                        for (int k = 0; k < 8; ++k) {
+                            Node* e = cur->slot[k ^ B.sign];
+                            if (!e) continue;
+                            const bool hitb = tight ? beam_box_tight(B, e->fmin, e->fmax) : beam_box(B, e->fmin, e->fmax);
+                            if (!hitb) continue;
+                            if (e->count <= leaf_size) {
+                                touched += 1;
+                                group.clear();
+                                subtree_shapes(e, &group);
+                                for (size_t k2 = b0; k2 < b1; ++k2) {
+                                    if (occ[k2]) continue;
+                                    o.ray_leafbox += 1;
+                                    if (!slab_f32(srs[k2 - b0], e->fmin, e->fmax, 0.01f, dist[k2])) continue;
+                                    o.ray_leafpass += 1;
+                                    for (int shape : group) {
+                                        o.ray_shape += 1;
+                                        const Hit<float> shh = T.shapes[(size_t)shape].kind == RT_SHAPE_TRIANGLE
+                                                                   ? triangle_occludes_f32(T.shapes[(size_t)shape], shape, rays[k2], 0.01f, dist[k2])
+                                                                   : shape_hit(T, shape, rays[k2], 0.01f, dist[k2]);
+                                        if (shh.t > 0.0f && shh.t <= dist[k2]) { occ[k2] = 1; --undecided; break; }
+                                    }
+                                }
+                            } else pending[np++] = e;
+                        }
+                        for (int q = np - 1; q >= 1; --q) stack.push_back(pending[q]);
+                        if (np > 0) { cur = pending[0]; continue; }
+                        if (stack.empty()) break;
+                        cur = stack.back(); stack.pop_back();
+                    }
+                }
+                for (size_t k = 0; k < rays.size(); ++k)
+                    if ((bool)occ[k] != (bool)base_occ[k]) { g_err = "beam walk disagrees with per-ray walk"; return -1; }
+                o.grp_visits += visits; o.grp_touched += touched;
+                if (touched == 0) o.empty_walk_pairs += 1;
+                per_light[li].push_back({bmax, visits, touched});
+                if (rec && nr < rec_cap) {
+                    float* q = rec + nr * 8;
+                    q[0] = (float)rays.size(); q[1] = (float)nocc; q[2] = (float)pair_inner; q[3] = (float)pair_leaf;
+                    q[4] = (float)visits; q[5] = (float)touched; q[6] = (float)hit.shape; q[7] = (float)li;
+                    ++nr;
+                }
+            }
+        }
+    for (auto& v : per_light)
+        for (size_t q = 0; q < v.size(); q += 4) {
+            double a = 0, b = 0, c = 0;
+            for (size_t k = q; k < std::min(v.size(), q + 4); ++k) { a = std::max(a, v[k].base_max); b = std::max(b, v[k].visits); c = std::max(c, v[k].touched); }
+            o.wave_base_iters += a; o.wave_grp_visits += b; o.wave_grp_touched += c; o.waves += 1;
+        }
+    *out = o;
+    if (n_rec) *n_rec = nr;
+    return 0;
+}
+
+// ---- second experiment: occluder hints -------------------------------------------------------------------
+// The repetitions of a pair run one after another; a repetition that found an occluder leaves a hint (the
+// ancestor block `up` levels above the leaf that held it); the next repetitions walk that subtree first and
+// only walk from the root when it holds no hit.
+namespace {
+struct WalkResult { bool hit; Node* leaf; double inner, shapes; };
+WalkResult walk_from(const Scene& sc, Node* start, const Ray<float>& r, float tmin, float tmax) {
+    const StackRay sr = make_stack_ray(r);
+    WalkResult w{false, nullptr, 0, 0};
+    std::vector<Node*> stack;
+    std::vector<int> group;
+    const int leaf_size = sc.leaf_size;
+    Node* cur = start;
+    for (;;) {
+        w.inner += 1;
+        Node* pending[8]; int np = 0;
+        Node* leaves[8]; int nl = 0;
+        for (int k = 0; k < 8; ++k) {
+            Node* e = cur->slot[k ^ sr.sign];
+            if (!e) continue;
+            if (!slab_f32(sr, e->fmin, e->fmax, tmin, tmax)) continue;
+            if (e->count <= leaf_size) leaves[nl++] = e; else pending[np++] = e;
+        }
+        for (int q = 0; q < nl; ++q) {
+            group.clear();
+            subtree_shapes(leaves[q], &group);
+            for (int shape : group) {
+                w.shapes += 1;
+                const Hit<float> sh = sc.t32.shapes[(size_t)shape].kind == RT_SHAPE_TRIANGLE
+                                          ? triangle_occludes_f32(sc.t32.shapes[(size_t)shape], shape, r, tmin, tmax)
+                                          : shape_hit(sc.t32, shape, r, tmin, tmax);
+                if (sh.t > 0.0f && sh.t <= tmax) { w.hit = true; w.leaf = leaves[q]; return w; }
+            }
+        }
+        for (int i = np - 1; i >= 1; --i) stack.push_back(pending[i]);
+        if (np > 0) { cur = pending[0]; continue; }
+        if (stack.empty()) break;
+        cur = stack.back();
+        stack.pop_back();
+    }
+    return w;
+}
+}  // namespace
+
+// out: [0] rays, [1] today's visits, [2] today's shape tests, [3] hinted visits, [4] hinted shape tests,
+//      [5] rays that had a hint, [6] hints that held a hit
+extern "C" int sim_hints(const orc_scene* s, const rt_image_spec* spec, uint64_t seed, int up, double* out) {
+    const Scene& sc = s->sc;
+    const int W = spec->width, H = spec->height, reps = spec->soft_shadow_monte_carlo_repetitions;
+    const CameraF64 c64 = new_camera(sc, W, H);
+    const Camera<float> cf = narrow_camera<float>(c64);
+    const Tables<float>& T = sc.t32;
+    Node* root = effective(sc.wide_root);
+    const int leaf_size = sc.leaf_size;
+    // parent links of the block tree
+    std::unordered_map<Node*, Node*> parent;
+    {
+        std::vector<Node*> st{root};
+        while (!st.empty()) {
+            Node* n = st.back(); st.pop_back();
+            for (Node* e : n->slot) if (e) { parent[e] = n; if (e->count > leaf_size) st.push_back(e); }
+        }
+    }
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (int row = 0; row < H; ++row)
+        for (int i = 0; i < W; ++i) {
+            const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(row * W + i), 0u};
+            const Ray<float> r = camera_ray(cf, W, H, i, H - 1 - row, key);
+            Hit<float> hit;
+            if (!trace_stack_f32(sc, r, 0.0f, FLT_MAX, false, hit, nullptr)) continue;
+            const Shape<float>& sh = T.shapes[hit.shape];
+            const Material<float>& m = T.materials[sh.material];
+            if (m.kind != RT_MAT_PHONGBLINN) continue;
+            int lpos = -1;
+            for (size_t li = 0; li < T.lights.size(); ++li) {
+                const Light<float>& L = T.lights[li];
+                if (L.kind == RT_LIGHT_AMBIENT) continue;
+                ++lpos;
+                const V3<float> l2p = sub(L.pos, hit.p);
+                const V3<float> ldir = unit(l2p);
+                const float inten = saturate(dot(hit.normal, ldir));
+                const V3<float> h = unit(add(ldir, r.d));
+                const float si = std::pow(saturate(dot(hit.normal, h)), m.param);
+                if (inten == 0.0f && (si == 0.0f || (m.spec.x == 0 && m.spec.y == 0 && m.spec.z == 0))) continue;
+                Node* hint = nullptr;
+                for (int k = 0; k < reps; ++k) {
+                    const V3<float> jit = scale(0.25f, random_in_unit_sphere<float>(key, 0, P_SHADOW, (uint32_t)(lpos * reps + k)));
+                    const V3<float> shifted = add(L.pos, jit);
+                    if (L.kind == RT_LIGHT_SPOT && !(dot(L.look_dir, unit(sub(hit.p, shifted))) >= L.cos_angle)) continue;
+                    const V3<float> ld = sub(shifted, hit.p);
+                    const float d = norm(ld);
+                    const Ray<float> ray{hit.p, scale(1.0f / d, ld)};
+                    out[0] += 1;
+                    const WalkResult base = walk_from(sc, root, ray, 0.01f, d);
+                    out[1] += base.inner; out[2] += base.shapes;
+                    bool done = false;
+                    if (hint) {
+                        out[5] += 1;
+                        const WalkResult w = walk_from(sc, hint, ray, 0.01f, d);
+                        out[3] += w.inner; out[4] += w.shapes;
+                        if (w.hit) { out[6] += 1; done = true; if (!base.hit) { g_err = "hint found a hit the full walk did not"; return -1; } }
+                    }
+                    if (!done) {
+                        out[3] += base.inner; out[4] += base.shapes;
+                        if (base.hit) {
+                            Node* a = parent[base.leaf];
+                            for (int u = 0; u < up && a != root; ++u) a = parent[a];
+                            hint = a;
+                        }
+                    }
+                }
+            }
+        }
+    return 0;
+}

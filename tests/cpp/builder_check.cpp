@@ -6,8 +6,11 @@
 //     every record of its block (so no ray can miss a shape by culling a box);
 //   - record / block indices are in range, blocks hold 1..8 records in slot order;
 //   - walking the blocks depth-first never needs more stack than FlatTree::stack_bound;
+//   - every quantised block (QBlock, the shadow-ray walk's copy of the tree) decodes, in exact arithmetic, to boxes
+//     that enclose the child records' fp32 boxes, names the same leaf shapes and the blocks of the same inner children;
 //   - the SAH tree of a scene long enough for the builder's threads (chunked sweeps and forked halves) is
 //     byte-identical for 1, 3 and 7 threads.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -72,6 +75,47 @@ static void walk(const FlatTree& t, uint32_t ref, int stack, const ChildRecord* 
     }
 }
 
+// Walks records and QBlocks side by side: block `ref` of the record tree must be block `blk` of the quantised tree.
+static void walk_q(const FlatTree& t, uint32_t ref, uint32_t blk, size_t* visited) {
+    ++*visited;
+    CHECK((size_t)(blk + 1) * kQBlockWords <= t.qblocks.size(), "qblock %u out of range", blk);
+    if ((size_t)(blk + 1) * kQBlockWords > t.qblocks.size()) return;
+    const uint32_t* w = t.qblocks.data() + (size_t)blk * kQBlockWords;
+    const uint32_t first = ref >> 8, present = ref & 0xffu;
+    CHECK((w[3] >> 24) == present, "qblock %u: present mask %02x, records say %02x", blk, w[3] >> 24, present);
+    float origin[3];
+    std::memcpy(origin, w, 12);
+    const uint8_t* meta = reinterpret_cast<const uint8_t*>(w + 6);
+    const uint8_t* qlo = reinterpret_cast<const uint8_t*>(w + 8);
+    const uint8_t* qhi = reinterpret_cast<const uint8_t*>(w + 14);
+    uint32_t leafm = 0, shape = w[5], rank = 0;
+    int k = 0;
+    for (int o = 0; o < 8; ++o) {
+        if (!((present >> o) & 1u)) { CHECK(meta[o] == 0, "qblock %u: absent slot %d has meta %u", blk, o, meta[o]); continue; }
+        const ChildRecord& r = t.records[first + (size_t)k++];
+        for (int a = 0; a < 3; ++a) {
+            const int e = (int)((w[3] >> (8 * a)) & 0xffu);
+            CHECK(e >= 1 && e <= 254, "qblock %u: exponent %d", blk, e);
+            const double step = std::ldexp(1.0, e - 127);
+            const double lo = (double)origin[a] + qlo[8 * a + o] * step, hi = (double)origin[a] + qhi[8 * a + o] * step;
+            CHECK(lo <= (double)r.bmin[a] && hi >= (double)r.bmax[a], "qblock %u slot %d axis %d: [%g, %g] does not enclose [%g, %g]", blk, o, a, lo, hi,
+                  (double)r.bmin[a], (double)r.bmax[a]);
+            CHECK((double)r.bmin[a] - lo < step && hi - (double)r.bmax[a] < step, "qblock %u slot %d axis %d: more than one grid step of slack", blk, o, a);
+        }
+        if (r.w1 & kLeafFlag) {
+            leafm |= 1u << o;
+            CHECK((r.w0 >> 8) == shape && (r.w0 & 0xffu) == (meta[o] & 0x1fu) && (meta[o] >> 5) == 0, "qblock %u slot %d: leaf %u+%u, record says %u+%u", blk, o,
+                  shape, meta[o] & 0x1fu, r.w0 >> 8, r.w0 & 0xffu);
+            shape += meta[o] & 0x1fu;
+        } else {
+            CHECK((meta[o] & 0x1fu) == 0 && (uint32_t)(meta[o] >> 5) == rank, "qblock %u slot %d: inner rank %u, expected %u", blk, o, meta[o] >> 5, rank);
+            walk_q(t, r.w0, (w[4] & 0xffffffu) + rank, visited);
+            ++rank;
+        }
+    }
+    CHECK((w[4] >> 24) == leafm, "qblock %u: leaf mask %02x, records say %02x", blk, w[4] >> 24, leafm);
+}
+
 static void check_scene(const char* name, const std::vector<rt_shape>& shapes, int leaf_size) {
     for (int kind = 0; kind < 2; ++kind) {
         const std::vector<HostNode> nodes = kind == 0 ? build_sah(shapes.data(), (int64_t)shapes.size(), leaf_size)
@@ -85,6 +129,10 @@ static void check_scene(const char* name, const std::vector<rt_shape>& shapes, i
         for (size_t i = 0; i < shapes.size(); ++i) CHECK(seen[i] == 1, "%s (%s): shape %zu is in %d leaves", name, kind ? "octree" : "sah", i, seen[i]);
         CHECK(max_stack < t.stack_bound, "%s: walk needs %d stack entries, bound %d", name, max_stack, t.stack_bound);
         CHECK(t.order.size() == shapes.size(), "%s: order has %zu entries", name, t.order.size());
+        size_t qvisited = 0;
+        if (!shapes.empty()) walk_q(t, t.root_ref, 0, &qvisited);
+        CHECK(t.qblocks.size() == (size_t)std::max<long long>(1, (long long)t.n_inner) * kQBlockWords && (shapes.empty() || qvisited == (size_t)t.n_inner),
+              "%s: %zu quantised words, %zu blocks reached, %lld blocks", name, t.qblocks.size(), qvisited, (long long)t.n_inner);
         std::printf("%-28s %-6s leaf %d: %6zu shapes %6lld blocks %7zu records depth %2d stack %2d (bound %2d)\n", name, kind ? "octree" : "sah",
                     leaf_size, shapes.size(), (long long)t.n_inner, t.records.size(), t.depth, max_stack, t.stack_bound);
     }
@@ -130,6 +178,7 @@ int main() {
             CHECK(flatten_octree(build_sah(v.data(), (int64_t)v.size(), 6), 6, &t, &err), "flatten failed: %s", err ? err : "?");
             if (threads[0] == '1') { ref = t; continue; }
             CHECK(t.records.size() == ref.records.size() && t.order == ref.order && t.root_ref == ref.root_ref && t.stack_bound == ref.stack_bound &&
+                      t.qblocks == ref.qblocks &&
                       std::memcmp(t.records.data(), ref.records.data(), t.records.size() * sizeof(ChildRecord)) == 0,
                   "SAH tree differs between 1 and %s threads", threads);
         }
