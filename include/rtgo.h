@@ -37,7 +37,9 @@ extern "C" {
 #define RT_ERR_DEVICE (-2)    /* HIP runtime error or no gfx950 device                */
 #define RT_ERR_ALGORITHM (-3) /* unknown BvhTraversalAlgorithm: the reference panics, */
                               /* accelerationstructures.go:73                         */
-#define RT_ERR_LIMIT (-4)     /* scene exceeds a documented capacity limit            */
+#define RT_ERR_LIMIT (-4)     /* scene exceeds a documented capacity limit: fewer than */
+                              /* 2^24 shapes and 2^24 child records per scene, 2^31-1  */
+                              /* pixels, depth <= 2^20, repetitions <= 65536           */
 
 typedef struct rt_vec3 { double x, y, z; } rt_vec3; /* r3.Vec */
 
@@ -171,8 +173,11 @@ int rt_render(rt_scene* scene, const rt_image_spec* spec, const rt_partition* pa
  * (width*height*3 floats, row 0 = top) of this rank's share are ADDED into
  * d_accum_rgb, a DEVICE pointer owned by the caller (e.g. a torch tensor that is then
  * reduced over RCCL).  hip_stream: hipStream_t to enqueue on (NULL = default stream).
- * The call returns after the work has been enqueued and the stats have been read back
- * (it synchronises the stream only when stats != NULL). */
+ * The call BLOCKS for most of the frame: the host waits once per bounce of every batch for
+ * the queue lengths (on an event recorded before that bounce's shadow rays, so the stream
+ * itself never drains).  With stats != NULL it returns when the frame is complete; with
+ * stats == NULL it returns once the last batch is enqueued, its tail still running on the
+ * stream. */
 int rt_render_accum_device(rt_scene* scene, const rt_image_spec* spec, const rt_partition* part,
                            float* d_accum_rgb, void* hip_stream, rt_stats* stats);
 
@@ -202,6 +207,15 @@ int rt_trace_rays(rt_scene* scene, const float* rays, int64_t n, int32_t any_hit
  * reference — writes {ox,oy,oz,dx,dy,dz} * n.  pixels: n * 3 int32 {i, j, s}. */
 int rt_camera_rays(rt_scene* scene, const rt_image_spec* spec, uint64_t seed,
                    const int32_t* pixels, int64_t n, float* rays_out);
+
+/* Parity entry point: material.scatter (material.go:34-132) of the nearest hit of explicit rays,
+ * as color() evaluates it at raytracer.go:146.  rays: n * 6 floats {o, d}; keys: n * 3 uint32
+ * {pixel index, sample index, bounce} = the Philox counter words of the path the ray belongs to.
+ * out: n * 20 floats {shouldTrace, attenuation.xyz, scattered origin.xyz, scattered direction.xyz,
+ * terminal colour.xyz, t, hit point.xyz, normal.xyz}; a miss gives zeros and t = -1.  PhongBlinn
+ * hits trace their soft-shadow rays (spec->soft_shadow_monte_carlo_repetitions per light). */
+int rt_scatter_probe(rt_scene* scene, const rt_image_spec* spec, uint64_t seed, const float* rays,
+                     const uint32_t* keys, int64_t n, float* out);
 
 #ifdef __cplusplus
 }

@@ -623,7 +623,7 @@ template <class R> inline Hit<R> triangle_hit(const Shape<R>& tr, int idx, const
     if (t < tmin || t > tmax) return {(R)-1, {}, {}, -1};
     return {t, point_at(r, t), unit(cross(e1, e2)), idx};
 }
-// Device shadow-ray form (device_math.hpp triangle_occludes): fused, division-free; t only on a hit.
+// Device shadow-ray form (device_math.hpp triangle_occludes): fused, division-free, a yes/no answer.
 inline float dotf(const V3<float>& a, const V3<float>& b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 inline V3<float> crossf(const V3<float>& a, const V3<float>& b) {
     return {fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
@@ -646,10 +646,11 @@ inline Hit<float> triangle_occludes_f32(const Shape<float>& tr, int idx, const R
     sb &= 0x80000000u;
     const float ad = flip(det, sb);
     const float us = flip(dotf(tvec, pvec), sb), vs = flip(dotf(r.d, qvec), sb), ts = flip(dotf(e2, qvec), sb);
+    // the device never forms t = ts / ad: t > 0 is ts > 0, the interval is compared against ad
     const bool hit = ad > 0.0f && !(tr.single_sided && sb) && us >= 0.0f && vs >= 0.0f && us + vs <= ad &&
-                     ts >= tmin * ad && ts <= tmax * ad;
+                     ts >= tmin * ad && ts <= tmax * ad && ts > 0.0f;
     if (!hit) return {-1.0f, {}, {}, -1};
-    return {ts / ad, {}, {}, idx};
+    return {tmax, {}, {}, idx};  // any accepted value: an occluder's t is not used (light.go:141-160 as any-hit)
 }
 template <class R> inline Hit<R> shape_hit(const Tables<R>& T, int idx, const Ray<R>& r, R tmin, R tmax) {
     const Shape<R>& s = T.shapes[idx];

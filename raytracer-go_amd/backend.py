@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_CSRC, "librtgo_hip.so")
 # every extern "C" symbol include/rtgo.h declares
 SYMBOLS = ("rt_last_error", "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info",
            "rt_render", "rt_render_accum_device", "rt_render_accum", "rt_resolve_device",
-           "rt_generate_image", "rt_trace_rays", "rt_camera_rays")
+           "rt_generate_image", "rt_trace_rays", "rt_camera_rays", "rt_scatter_probe")
 
 
 class RtgoError(RuntimeError):
@@ -57,6 +57,7 @@ def lib():
         L.rt_generate_image.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
         L.rt_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p]
+        L.rt_scatter_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         _lib = L
     return _lib
 
@@ -136,6 +137,16 @@ class DeviceScene:
         t = np.empty(n, dtype=np.float32)
         _check(lib().rt_trace_rays(self._h, rays.ctypes.data, n, 1 if any_hit else 0, prim.ctypes.data, t.ctypes.data))
         return prim, t
+
+    def scatter_probe(self, spec, rays6, keys, seed=0x5EED):
+        """material.scatter of the nearest hit of each ray: rays6 (n, 6) {o, d}, keys (n, 3) {pixel, sample, bounce}
+        -> (n, 20) float32 {shouldTrace, attenuation, scattered o, scattered d, colour, t, p, normal}."""
+        s = _abi.image_spec(spec)
+        rays6 = np.ascontiguousarray(rays6, dtype=np.float32)
+        keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        out = np.zeros((rays6.shape[0], 20), dtype=np.float32)
+        _check(lib().rt_scatter_probe(self._h, C.addressof(s), seed, rays6.ctypes.data, keys.ctypes.data, rays6.shape[0], out.ctypes.data))
+        return out
 
     def camera_rays(self, spec, pixels, seed=0x5EED):
         s = _abi.image_spec(spec)

@@ -129,14 +129,14 @@ RT_DEV float triangle_hit(f3 A, f3 e1, f3 e2, bool single_sided, f3 o, f3 d, flo
 }
 // Shadow rays only need "is there a hit with tmin <= t <= tmax": the same Moller-Trumbore quantities,
 // but fused (explicit fmaf) and without the division — u, v, t are compared against |det| instead of
-// being scaled by 1/det, and t is divided out only for an actual hit.  The outcome can differ from
+// being scaled by 1/det.  The outcome can differ from
 // triangle_hit's only for a ray within a rounding error of an edge or of tmin/tmax; nearest-hit rays
 // (whose t, shape and barycentrics are visible in the image) keep the reference's expression order.
 RT_DEV float dotf(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 RT_DEV f3 crossf(f3 a, f3 b) {
     return mk3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
-RT_DEV float triangle_occludes(f3 A, f3 e1, f3 e2, bool single_sided, f3 o, f3 d, float tmin, float tmax) {
+RT_DEV bool triangle_occludes(f3 A, f3 e1, f3 e2, bool single_sided, f3 o, f3 d, float tmin, float tmax) {
     const f3 pvec = crossf(d, e2);
     const float det = dotf(e1, pvec);
     const f3 tvec = sub3(o, A);
@@ -146,28 +146,40 @@ RT_DEV float triangle_occludes(f3 A, f3 e1, f3 e2, bool single_sided, f3 o, f3 d
     const float us = __uint_as_float(__float_as_uint(dotf(tvec, pvec)) ^ sb);
     const float vs = __uint_as_float(__float_as_uint(dotf(d, qvec)) ^ sb);
     const float ts = __uint_as_float(__float_as_uint(dotf(e2, qvec)) ^ sb);
-    const bool hit = ad > 0.0f && !(single_sided && sb) && us >= 0.0f && vs >= 0.0f && us + vs <= ad &&
-                     ts >= tmin * ad && ts <= tmax * ad;
-    return hit ? ts / ad : -1.0f;
+    // t = ts / ad is never formed: t > 0 is ts > 0, tmin <= t <= tmax is compared against ad
+    return ad > 0.0f && !(single_sided && sb) && us >= 0.0f && vs >= 0.0f && us + vs <= ad &&
+           ts >= tmin * ad && ts <= tmax * ad && ts > 0.0f;
 }
-template <bool ANY>
-RT_DEV float prim_hit(const DScene& S, uint32_t prim, f3 o, f3 d, float tmin, float tmax) {
-    // all three quads are fetched together (a sphere ignores p1): one memory latency per shape
-    float4 p0 = S.tprims[3 * (size_t)prim];
-    float4 p1 = S.tprims[3 * (size_t)prim + 1];
-    float4 p2 = S.tprims[3 * (size_t)prim + 2];
+// all three quads of a shape are fetched together (a sphere ignores p1): one memory latency per shape
+struct PrimQuads { float4 p0, p1, p2; };
+RT_DEV PrimQuads load_tprim(const DScene& S, uint32_t prim) {
+    PrimQuads q;
+    q.p0 = S.tprims[3 * (size_t)prim];
+    q.p1 = S.tprims[3 * (size_t)prim + 1];
+    q.p2 = S.tprims[3 * (size_t)prim + 2];
     // keeps the compiler from sinking the p1 / p2 loads below the triangle-or-sphere branch, which would
     // make them a second, dependent memory round trip per shape
-    asm volatile("" : "+v"(p0.x), "+v"(p1.x), "+v"(p2.x), "+v"(p2.y));
-    const uint32_t bits = __float_as_uint(p2.y);
-    if (bits & kPrimTriangle) {
-        if (ANY)
-            return triangle_occludes(mk3(p0.x, p0.y, p0.z), mk3(p0.w, p1.x, p1.y), mk3(p1.z, p1.w, p2.x),
-                                     (bits & kPrimSingleSided) != 0, o, d, tmin, tmax);
-        return triangle_hit(mk3(p0.x, p0.y, p0.z), mk3(p0.w, p1.x, p1.y), mk3(p1.z, p1.w, p2.x),
+    asm volatile("" : "+v"(q.p0.x), "+v"(q.p1.x), "+v"(q.p2.x), "+v"(q.p2.y));
+    return q;
+}
+// nearest-hit rays: t of the hit inside (tmin, tmax] / [tmin, tmax], or -1
+RT_DEV float prim_hit(const DScene& S, uint32_t prim, f3 o, f3 d, float tmin, float tmax) {
+    const PrimQuads q = load_tprim(S, prim);
+    const uint32_t bits = __float_as_uint(q.p2.y);
+    if (bits & kPrimTriangle)
+        return triangle_hit(mk3(q.p0.x, q.p0.y, q.p0.z), mk3(q.p0.w, q.p1.x, q.p1.y), mk3(q.p1.z, q.p1.w, q.p2.x),
                             (bits & kPrimSingleSided) != 0, o, d, tmin, tmax);
-    }
-    return sphere_hit(p0, o, d, tmin, tmax);
+    return sphere_hit(q.p0, o, d, tmin, tmax);
+}
+// shadow rays: is there a hit with t > 0 inside the interval (the traversal's acceptance rule, light.go:141-160)
+RT_DEV bool prim_occludes(const DScene& S, uint32_t prim, f3 o, f3 d, float tmin, float tmax) {
+    const PrimQuads q = load_tprim(S, prim);
+    const uint32_t bits = __float_as_uint(q.p2.y);
+    if (bits & kPrimTriangle)
+        return triangle_occludes(mk3(q.p0.x, q.p0.y, q.p0.z), mk3(q.p0.w, q.p1.x, q.p1.y), mk3(q.p1.z, q.p1.w, q.p2.x),
+                                 (bits & kPrimSingleSided) != 0, o, d, tmin, tmax);
+    const float t = sphere_hit(q.p0, o, d, tmin, tmax);
+    return t > 0.0f && t <= tmax;
 }
 
 // ---- optional loop instrumentation (make prof -> librtgo_prof.so, scripts/prof_loops.py) ----
@@ -214,6 +226,8 @@ constexpr int kPendCap = RTGO_PEND_CAP;        // leaves a lane can hold back (o
 constexpr int kFlushLanes = RTGO_FLUSH_LANES;  // occluded(): run the shared shape loop when this many lanes hold leaves
 constexpr int kFlushLanesNearest = 64;         // traverse(): every lane loops over its own shapes, so wait for all
 constexpr int kLdsPerLane = kLdsStackDepth + kPendCap + 1;  // +1: the branch-free append stores one past the last
+static_assert(kPendCap >= 8, "one block visit can queue 8 leaves: a smaller queue is overrun (and then names shapes that do not exist)");
+static_assert(kLdsStackDepth >= 1 && kVisitBatch >= 1 && 8 % kVisitBatch == 0, "bad traversal knobs");
 struct TraceStack {
     uint32_t* lds;        // &s_stack[threadIdx.x], entries kBlock apart: [0, kLdsStackDepth) stack, then the leaf queue
     uint32_t* overflow;   // &overflow[global thread], entries `stride` apart (worst-case depth)
@@ -355,7 +369,7 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
             RT_PROF_POINT(1);  // shape tests
             const uint32_t prim = pnext++;
             --pleft;
-            const float t = prim_hit<false>(S, prim, o, d, tmin, best);
+            const float t = prim_hit(S, prim, o, d, tmin, best);
             if (t > 0.0f && t < best) { best = t; best_prim = (int)prim; }
         }
         npend = 0;
@@ -579,8 +593,7 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
                 uint32_t g = item - first_excl;  // which of the owner's shapes
                 for (uint32_t q = 1; g >= (leaf & 0xffu); ++q) { g -= leaf & 0xffu; leaf = oq[q * st.lds_stride]; }
                 RT_PROF_POINT(1);  // shape tests
-                const float t = prim_hit<true>(S, (leaf >> 8) + g, oo, dd, tmn, tmx);
-                if (t > 0.0f && t <= tmx) flag[owner] = 1u;
+                if (prim_occludes(S, (leaf >> 8) + g, oo, dd, tmn, tmx)) flag[owner] = 1u;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -92,8 +92,9 @@ struct Work {
     uint32_t* pairs; // (hit, light) pairs whose shading term is not exactly zero: light * n_hits + hit, light-major
     uint32_t* pair_seg;    // the same before compaction: light l's hits at [l * n_hits, l * n_hits + light_count[l])
     uint32_t* light_count; // [0, L) pairs per positional light, [L, 2L) their exclusive prefix sums
-    uint32_t* counters;  // [0..D] ray-queue sizes per bounce, [D+1..2D] phong-queue sizes, [2D+2..3] shadow rays (u64),
+    uint32_t* counters;  // per batch: [0..D] ray-queue sizes per bounce, [D+1..2D] phong-queue sizes,
                          // [2D+4..3D+3] pair-queue sizes per bounce
+    unsigned long long* frame_counters;  // per call: [0] shadow rays traced
     uint32_t* overflow;  // traversal stack spill
     uint32_t overflow_stride;
 };
@@ -169,8 +170,11 @@ __device__ __forceinline__ uint32_t xcd_block() {
     return (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
 }
 
-__global__ __launch_bounds__(kBlock) void k_extend(DScene S, Work Wk, const uint32_t* queue, uint32_t n) {
+// The queue lengths live in Wk.counters: the host launches on an upper bound (the previous bounce's length) and
+// every kernel reads the real one, so no launch waits for a read-back.
+__global__ __launch_bounds__(kBlock) void k_extend(DScene S, Work Wk, const uint32_t* queue, const uint32_t* n_ptr) {
     __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
+    const uint32_t n = *n_ptr;
     // (plain block order here: with xcd_block() the XCDs get image regions of unequal cost, 12.1 -> 15.9 ms per frame)
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlock;
@@ -185,10 +189,43 @@ __global__ __launch_bounds__(kBlock) void k_extend(DScene S, Work Wk, const uint
     }
 }
 
+// Metal.scatter (material.go:43-50) and Dielectric.scatter (material.go:52-70): the continuation ray and its attenuation
+struct Scattered { bool cont; f3 o, d, att; };
+RT_DEV Scattered scatter_specular(const DMaterial& m, f3 d, f3 p, f3 nrm, const RngKey& key, uint32_t bounce) {
+    Scattered r;
+    r.cont = false; r.o = p; r.d = d; r.att = mk3(1.0f, 1.0f, 1.0f);
+    if (m.kind == RT_MAT_METAL) {
+        const float fuzz = m.param < 1.0f ? m.param : 1.0f;
+        const f3 refl = reflected(d, nrm);
+        const f3 rnd = random_in_unit_sphere(key, bounce, P_FUZZ, 0);  // drawn even when it is not used
+        r.cont = dot3(refl, nrm) > 0.0f;                  // back face: terminal (0,0,0)
+        r.d = add3(refl, scale3(fuzz, rnd));              // not re-normalised
+        r.o = p;                                          // origin = p, no epsilon
+        r.att = ld3(m.color);
+    } else {
+        const float ratio = dot3(d, nrm) > 0.0f ? m.param : 1.0f / m.param;
+        const float dt = dot3(scale3(-1.0f, d), nrm);
+        const float cos_theta = (1.0f < dt) ? 1.0f : dt;
+        const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        const bool cannot = ratio * sin_theta > 1.0f;
+        f3 dir;
+        if (cannot || schlick(cos_theta, ratio) > u01(draw(key, bounce, P_SCHLICK, 0, 0).x))
+            dir = reflected(d, nrm);
+        else
+            dir = refracted(d, nrm, ratio);
+        r.cont = true;
+        r.d = dir;
+        r.o = add3(p, scale3(0.00001f, dir));
+    }
+    return r;
+}
+
 // color() (raytracer.go:135-162) one bounce at a time + Standard/Metal/Dielectric scatter
-__global__ __launch_bounds__(kBlock) void k_shade(DScene S, Batch B, Work Wk, const uint32_t* queue, uint32_t n,
+__global__ __launch_bounds__(kBlock) void k_shade(DScene S, Batch B, Work Wk, const uint32_t* queue, const uint32_t* n_ptr,
                                                   uint32_t* next_queue, int bounce) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t n = *n_ptr;
+    if (blockIdx.x * kBlock >= n) return;  // whole block beyond the queue (the grid covers an upper bound)
     bool cont = false, phong = false;
     uint32_t slot = 0;
     if (i < n) {
@@ -213,35 +250,13 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, Batch B, Work Wk, co
             } else if (m.kind == RT_MAT_PHONGBLINN) {
                 phong = true;
             } else {
-                const f3 nrm = prim_normal(P, o, d, t);
                 const uint2 pk = Wk.path_key[slot];
                 const RngKey key{B.k0, B.k1, pk.x, pk.y};
-                if (m.kind == RT_MAT_METAL) {  // material.go:43-50
-                    const float fuzz = m.param < 1.0f ? m.param : 1.0f;
-                    const f3 refl = reflected(d, nrm);
-                    const f3 rnd = random_in_unit_sphere(key, (uint32_t)bounce, P_FUZZ, 0);
-                    if (dot3(refl, nrm) > 0.0f) {  // back face: terminal (0,0,0)
-                        const f3 nd = add3(refl, scale3(fuzz, rnd));  // not re-normalised
-                        Wk.ray_o[slot] = make_float4(p.x, p.y, p.z, 0.0f);  // origin = p, no epsilon
-                        Wk.ray_d[slot] = make_float4(nd.x, nd.y, nd.z, __int_as_float(-1));
-                        Wk.thr[slot] = make_float4(th.x * m.color[0], th.y * m.color[1], th.z * m.color[2], 0.0f);
-                        cont = true;
-                    }
-                } else {  // Dielectric, material.go:52-70
-                    const float ratio = dot3(d, nrm) > 0.0f ? m.param : 1.0f / m.param;
-                    const float dt = dot3(scale3(-1.0f, d), nrm);
-                    const float cos_theta = (1.0f < dt) ? 1.0f : dt;
-                    const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-                    const bool cannot = ratio * sin_theta > 1.0f;
-                    f3 dir;
-                    if (cannot || schlick(cos_theta, ratio) > u01(draw(key, (uint32_t)bounce, P_SCHLICK, 0, 0).x))
-                        dir = reflected(d, nrm);
-                    else
-                        dir = refracted(d, nrm, ratio);
-                    const f3 np = add3(p, scale3(0.00001f, dir));
-                    Wk.ray_o[slot] = make_float4(np.x, np.y, np.z, 0.0f);
-                    Wk.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, __int_as_float(-1));
-                    Wk.thr[slot] = make_float4(th.x * 1.0f, th.y * 1.0f, th.z * 1.0f, 0.0f);
+                const Scattered sc = scatter_specular(m, d, p, prim_normal(P, o, d, t), key, (uint32_t)bounce);
+                if (sc.cont) {
+                    Wk.ray_o[slot] = make_float4(sc.o.x, sc.o.y, sc.o.z, 0.0f);
+                    Wk.ray_d[slot] = make_float4(sc.d.x, sc.d.y, sc.d.z, __int_as_float(-1));
+                    Wk.thr[slot] = make_float4(th.x * sc.att.x, th.y * sc.att.y, th.z * sc.att.z, 0.0f);
                     cont = true;
                 }
             }
@@ -316,8 +331,10 @@ RT_DEV bool surely_outside_cone(const DLight& L, const f3& p) {
 // for every jittered light position.  Only the other pairs are queued for k_shadow, per light
 // (segment l of pair_seg), so that the queue k_pair_compact builds from the segments is light-major.
 // Every pair's visible-repetition count starts at 0 here.
-__global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, uint32_t n_hits) {
+__global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, const uint32_t* n_hits_ptr) {
     const uint32_t hit_i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t n_hits = *n_hits_ptr;
+    if (blockIdx.x * kBlock >= n_hits) return;
     const bool live = hit_i < n_hits;
     PhongHit h{};
     if (live) h = load_phong_hit(S, Wk, Wk.phong_queue[hit_i]);
@@ -345,8 +362,9 @@ __global__ void k_pair_offsets(Work Wk, int n_pos_lights, uint32_t* pair_counter
     }
     *pair_counter = run;
 }
-__global__ __launch_bounds__(kBlock) void k_pair_compact(Work Wk, uint32_t n_hits, int n_pos_lights) {
+__global__ __launch_bounds__(kBlock) void k_pair_compact(Work Wk, const uint32_t* n_hits_ptr, int n_pos_lights) {
     const unsigned long long idx = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t n_hits = *n_hits_ptr;
     if (idx >= (unsigned long long)n_hits * n_pos_lights) return;
     const uint32_t l = (uint32_t)(idx / n_hits);
     const uint32_t j = (uint32_t)(idx - (unsigned long long)l * n_hits);
@@ -359,9 +377,10 @@ __global__ __launch_bounds__(kBlock) void k_pair_compact(Work Wk, uint32_t n_hit
 #ifndef RTGO_SHADOW_WAVES
 #define RTGO_SHADOW_WAVES 5
 #endif
-__global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, Batch B, Work Wk, uint32_t n_hits, int bounce,
+__global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, Batch B, Work Wk, const uint32_t* n_hits_ptr, int bounce,
                                                    int group, int group_shift, const uint32_t* pair_counter) {
     __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
+    const uint32_t n_hits = *n_hits_ptr;
     __shared__ uint32_t s_wave[(kBlock / 64) * 128];
     const uint32_t gtid = xcd_block() * kBlock + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlock;
@@ -426,14 +445,14 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
     }
     // shadow rays actually traced: one 64-bit atomic per wavefront
     for (int off = 32; off > 0; off >>= 1) launched += __shfl_down(launched, off);
-    if (lane == 0 && launched) atomicAdd(reinterpret_cast<unsigned long long*>(Wk.counters + 2 * B.max_depth + 2), launched);
+    if (lane == 0 && launched) atomicAdd(Wk.frame_counters, launched);
 }
 
 
 // PhongBlinn.scatter (material.go:73-132) given the visible-repetition counts
-__global__ __launch_bounds__(kBlock) void k_phong(DScene S, Batch B, Work Wk, uint32_t n_hits) {
+__global__ __launch_bounds__(kBlock) void k_phong(DScene S, Batch B, Work Wk, const uint32_t* n_hits_ptr) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n_hits) return;
+    if (i >= *n_hits_ptr) return;
     const uint32_t slot = Wk.phong_queue[i];
     const PhongHit h = load_phong_hit(S, Wk, slot);
     f3 c = mk3(0.0f, 0.0f, 0.0f);
@@ -518,11 +537,144 @@ __global__ __launch_bounds__(kBlock) void k_camera_probe(DCamera cam, int W, int
     r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
 }
 
+// material.scatter (material.go:34-132) of one ray per lane, for the parity probes: nearest hit, then what the
+// shading stages compute for it.  out: 20 floats {should_trace, attenuation, scattered origin, scattered direction,
+// colour, t, p, normal}; a miss leaves zeros and t = -1.  PhongBlinn hits trace their soft-shadow rays here, all
+// 64 lanes of the wavefront together (occluded() shares its shape loop over the wavefront).
+__global__ __launch_bounds__(kBlock) void k_scatter_probe(DScene S, Work Wk, const float* rays, const uint32_t* keys, uint32_t n,
+                                                          uint32_t k0, uint32_t k1, int reps, float* out) {
+    __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
+    __shared__ uint32_t s_wave[(kBlock / 64) * 128];
+    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t gstride = gridDim.x * kBlock;
+    const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride, s_wave + (threadIdx.x >> 6) * 128};
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gstride) {  // wave-uniform trip count
+        const uint32_t i = base + threadIdx.x;
+        const bool live = i < n;
+        const float* q = rays + (size_t)(live ? i : 0u) * 6;
+        const uint32_t* kq = keys + (size_t)(live ? i : 0u) * 3;
+        const f3 o = mk3(q[0], q[1], q[2]), d = mk3(q[3], q[4], q[5]);
+        const RngKey key{k0, k1, kq[0], kq[1]};
+        const uint32_t bounce = kq[2];
+        float t = -1.0f; int prim = -1;
+        if (live) traverse(S, st, o, d, 0.0f, &t, &prim);
+        float r[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) r[k] = 0.0f;
+        r[13] = -1.0f;
+        bool phong = false;
+        PhongHit h{};
+        if (live && prim >= 0) {
+            const PrimData P = load_prim(S, prim);
+            const DMaterial m = S.materials[__float_as_uint(P.p2.y) >> 2];
+            const f3 p = add3(o, scale3(t, d));
+            const f3 nrm = prim_normal(P, o, d, t);
+            r[13] = t; r[14] = p.x; r[15] = p.y; r[16] = p.z; r[17] = nrm.x; r[18] = nrm.y; r[19] = nrm.z;
+            if (m.kind == RT_MAT_STANDARD) {
+                f3 col = ld3(m.color);
+                if (m.texture >= 0) {
+                    float u, v;
+                    texture_map(P, p, &u, &v);
+                    col = texture_color(S.textures[m.texture], u, v);
+                }
+                r[4] = p.x; r[5] = p.y; r[6] = p.z;
+                r[10] = col.x; r[11] = col.y; r[12] = col.z;
+            } else if (m.kind == RT_MAT_PHONGBLINN) {
+                phong = true;
+                h.p = p; h.nrm = nrm; h.d = d; h.m = m; h.mc = ld3(m.color);
+                if (m.texture >= 0) {
+                    float u, v;
+                    texture_map(P, p, &u, &v);
+                    h.mc = texture_color(S.textures[m.texture], u, v);
+                }
+            } else {
+                const Scattered sc = scatter_specular(m, d, p, nrm, key, bounce);
+                r[0] = sc.cont ? 1.0f : 0.0f;
+                r[1] = sc.att.x; r[2] = sc.att.y; r[3] = sc.att.z;
+                r[4] = sc.o.x; r[5] = sc.o.y; r[6] = sc.o.z;
+                r[7] = sc.d.x; r[8] = sc.d.y; r[9] = sc.d.z;
+            }
+        }
+        // PhongBlinn.scatter (material.go:73-132) with the rules of k_phong_pairs / k_shadow / k_phong
+        f3 c = mk3(0.0f, 0.0f, 0.0f);
+        uint32_t lp = 0;
+        for (int ql = 0; ql < S.n_lights; ++ql) {
+            const DLight L = S.lights[ql];
+            if (L.kind == RT_LIGHT_AMBIENT) {
+                c = add3(c, scale3(L.intensity, ld3(L.color)));
+                continue;
+            }
+            f3 comb = mk3(0.0f, 0.0f, 0.0f);
+            bool keep = false;
+            if (phong) {
+                comb = phong_term(L, h.m, h.mc, h.p, h.nrm, h.d);
+                keep = !(comb.x == 0.0f && comb.y == 0.0f && comb.z == 0.0f);
+            }
+            uint32_t visible = 0;
+            for (int rep = 0; rep < reps; ++rep) {
+                bool traced = false;
+                f3 dir = mk3(1.0f, 1.0f, 1.0f);
+                float dist = 0.0f;
+                if (keep) {
+                    const f3 jit = scale3(0.25f, random_in_unit_sphere(key, bounce, P_SHADOW, lp * (uint32_t)reps + (uint32_t)rep));
+                    const f3 shifted = add3(ld3(L.pos), jit);
+                    bool in_cone = true;
+                    if (L.kind == RT_LIGHT_SPOT) in_cone = dot3(ld3(L.look_dir), unit3(sub3(h.p, shifted))) >= L.cos_angle;
+                    if (in_cone) {
+                        traced = true;
+                        const f3 ld = sub3(shifted, h.p);
+                        dist = norm3(ld);
+                        dir = scale3(1.0f / dist, ld);
+                    }
+                }
+                const bool occ = occluded<true>(S, st, traced, h.p, dir, 0.01f, dist);
+                if (traced && !occ) ++visible;
+            }
+            if (visible > 0) c = add3(c, scale3((float)visible / (float)reps, comb));
+            ++lp;
+        }
+        if (phong) { r[10] = min1(c.x); r[11] = min1(c.y); r[12] = min1(c.z); }
+        if (live) {
+            float* w = out + (size_t)i * 20;
+#pragma unroll
+            for (int k = 0; k < 20; ++k) w[k] = r[k];
+        }
+    }
+}
+
 }  // namespace
 
 // ============================================================================================
 // Host runtime
 // ============================================================================================
+// A device buffer that is kept between calls and only ever grows (frame and probe buffers of the host-pointer
+// entry points: no hipMalloc / hipFree per call).
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        const hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+// Batch workspace of a render call: ONE device allocation, carved into the arrays of `Work`.
+struct Arena {
+    Work wk{};
+    unsigned char* base = nullptr;   // start of the allocation (owned: hipMalloc'd by the scene)
+    size_t bytes = 0;
+    bool owned = true;
+    int64_t paths = 0; int depth = 0, lpos = 0;  // what wk was carved for
+    unsigned long long overflow_entries = 0;     // (spill + 1) * stride
+    int grid_cap = kMaxGridBlocks;               // most blocks a grid-stride launch may use with this arena
+};
+
+constexpr int kSnapshots = 3;  // pinned copies of the counter block: two alternate per bounce, one for the end of a call
+
 struct rt_scene {
     int device = 0;
     DScene d{};
@@ -532,47 +684,84 @@ struct rt_scene {
     double ms_build = 0;
     // camera inputs (NewCamera needs the aspect ratio, so the camera is finished per render)
     rt_vec3 from, at, up; double aperture = 0, fov = 0;
-    // batch workspace, grown on demand
-    Work wk{}; int64_t wk_paths = 0; int wk_depth = 0; int wk_lpos = 0;
-    int spill = 0;  // traversal-stack entries beyond the LDS part (from the tree's exact worst case)
-    uint32_t* h_counters = nullptr;  // pinned
-    hipEvent_t ev[8] = {};
+    Arena arena;     // grown on demand
+    int spill = 0;   // traversal-stack entries beyond the LDS part (from the tree's exact worst case)
+    uint32_t* h_counters = nullptr;  // pinned, kSnapshots * h_counter_words
+    size_t h_counter_words = 0;
+    hipEvent_t ev_snap[2] = {}, ev_frame[2] = {};
     bool ev_ok = false;
+    std::vector<hipEvent_t> ev_pool;  // per-stage timing of a call that asks for stats: 4 per (batch, bounce), reused
+    DevBuf accum, rgba, probe_in, probe_out, probe_out2;
 };
 
 namespace {
 
-void free_work(rt_scene* s) {
-    Work& w = s->wk;
-    void* ptrs[] = {w.ray_o, w.ray_d, w.thr, w.rad, w.path_key, w.queue[0], w.queue[1], w.phong_queue, w.vis, w.pairs, w.pair_seg, w.light_count, w.counters};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
-    uint32_t* ov = w.overflow; const uint32_t os = w.overflow_stride;
-    w = Work{};
-    w.overflow = ov; w.overflow_stride = os;
-    s->wk_paths = 0;
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t n) { return (n + kAlign - 1) / kAlign * kAlign; }
+
+// Lays the arrays of a batch workspace out over `base` (nullptr: only measure).  Returns the bytes needed.
+size_t carve_work(Work* w, unsigned char* base, int64_t paths, int depth, int lpos, unsigned long long overflow_entries) {
+    size_t off = 0;
+    auto take = [&](size_t n) { unsigned char* p = base ? base + off : nullptr; off += align_up(n); return p; };
+    const size_t P = (size_t)paths, L = (size_t)(lpos > 0 ? lpos : 1);
+    w->ray_o = (float4*)take(P * sizeof(float4));
+    w->ray_d = (float4*)take(P * sizeof(float4));
+    w->thr = (float4*)take(P * sizeof(float4));
+    w->rad = (float4*)take(P * sizeof(float4));
+    w->path_key = (uint2*)take(P * sizeof(uint2));
+    w->queue[0] = (uint32_t*)take(P * sizeof(uint32_t));
+    w->queue[1] = (uint32_t*)take(P * sizeof(uint32_t));
+    w->phong_queue = (uint32_t*)take(P * sizeof(uint32_t));
+    w->vis = (uint32_t*)take(P * L * sizeof(uint32_t));
+    w->pairs = (uint32_t*)take(P * L * sizeof(uint32_t));
+    w->pair_seg = (uint32_t*)take(P * L * sizeof(uint32_t));
+    w->light_count = (uint32_t*)take(2 * L * sizeof(uint32_t));
+    w->counters = (uint32_t*)take((size_t)(3 * depth + 8) * sizeof(uint32_t));
+    w->frame_counters = (unsigned long long*)take(4 * sizeof(unsigned long long));
+    w->overflow = (uint32_t*)take((size_t)overflow_entries * sizeof(uint32_t));
+    return off;
 }
 
-int ensure_work(rt_scene* s, int64_t paths, int depth, int lpos) {
-    if (paths <= s->wk_paths && depth <= s->wk_depth && lpos <= s->wk_lpos) return RT_OK;
-    free_work(s);
-    Work& w = s->wk;
-    HIP_TRY(hipMalloc((void**)&w.ray_o, paths * sizeof(float4)));
-    HIP_TRY(hipMalloc((void**)&w.ray_d, paths * sizeof(float4)));
-    HIP_TRY(hipMalloc((void**)&w.thr, paths * sizeof(float4)));
-    HIP_TRY(hipMalloc((void**)&w.rad, paths * sizeof(float4)));
-    HIP_TRY(hipMalloc((void**)&w.path_key, paths * sizeof(uint2)));
-    HIP_TRY(hipMalloc((void**)&w.queue[0], paths * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&w.queue[1], paths * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&w.phong_queue, paths * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&w.vis, (size_t)paths * (size_t)(lpos > 0 ? lpos : 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&w.pairs, (size_t)paths * (size_t)(lpos > 0 ? lpos : 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&w.pair_seg, (size_t)paths * (size_t)(lpos > 0 ? lpos : 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&w.light_count, (size_t)2 * (size_t)(lpos > 0 ? lpos : 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&w.counters, (size_t)(3 * depth + 8) * sizeof(uint32_t)));
-    if (s->h_counters) { (void)hipHostFree(s->h_counters); s->h_counters = nullptr; }
-    HIP_TRY(hipHostMalloc((void**)&s->h_counters, (size_t)(3 * depth + 8) * sizeof(uint32_t)));
-    s->wk_paths = paths; s->wk_depth = depth; s->wk_lpos = lpos;
+// Blocks of the widest grid-stride launch over `lanes` work items, and the spill region that goes with it:
+// (spill + 1) entries for every thread of that grid.
+inline unsigned long long grid_blocks(unsigned long long lanes, int cap) {
+    unsigned long long blocks = (lanes + kBlock - 1) / kBlock;
+    if (blocks < 256) blocks = 256;
+    return blocks > (unsigned long long)cap ? (unsigned long long)cap : blocks;
+}
+
+int ensure_work(rt_scene* s, int64_t paths, int depth, int lpos, unsigned long long lanes) {
+    Arena& a = s->arena;
+    const unsigned long long stride = grid_blocks(lanes, a.grid_cap) * kBlock;
+    const unsigned long long entries = s->spill > 0 ? (unsigned long long)(s->spill + 1) * stride : 0ull;
+    if (a.base && paths <= a.paths && depth <= a.depth && lpos <= a.lpos && entries <= a.overflow_entries) {
+        a.wk.overflow_stride = (uint32_t)(a.overflow_entries / (unsigned long long)(s->spill + 1));
+        return RT_OK;
+    }
+    // grow, never shrink: a later, smaller call finds everything in place
+    const int64_t np = std::max(paths, a.paths);
+    const int nd = std::max(depth, a.depth), nl = std::max(lpos, a.lpos);
+    const unsigned long long ne = std::max(entries, a.overflow_entries);
+    Work w{};
+    const size_t need = carve_work(&w, nullptr, np, nd, nl, ne);
+    if (a.base) { (void)hipFree(a.base); a.base = nullptr; a.bytes = 0; a.paths = 0; a.depth = 0; a.lpos = 0; a.overflow_entries = 0; }
+    HIP_TRY(hipMalloc((void**)&a.base, need));
+    a.bytes = need;
+    (void)carve_work(&a.wk, a.base, np, nd, nl, ne);
+    a.paths = np; a.depth = nd; a.lpos = nl; a.overflow_entries = ne;
+    a.wk.overflow_stride = s->spill > 0 ? (uint32_t)(ne / (unsigned long long)(s->spill + 1)) : 0u;
+    const size_t words = (size_t)(3 * nd + 8);
+    if (words > s->h_counter_words) {
+        if (s->h_counters) { (void)hipHostFree(s->h_counters); s->h_counters = nullptr; s->h_counter_words = 0; }
+        HIP_TRY(hipHostMalloc((void**)&s->h_counters, kSnapshots * words * sizeof(uint32_t)));
+        s->h_counter_words = words;
+    }
     return RT_OK;
+}
+
+// Makes the spill region large enough for a probe launch over `lanes` rays (the render workspace is kept).
+int ensure_overflow(rt_scene* s, unsigned long long lanes) {
+    return ensure_work(s, std::max<int64_t>(1, s->arena.paths), std::max(1, s->arena.depth), std::max(1, s->arena.lpos), lanes);
 }
 
 // NewCamera, camera.go:18-35, with the arguments GenerateImage passes (raytracer.go:59-68)
@@ -617,23 +806,10 @@ int validate_spec(const rt_image_spec* spec) {
     return RT_OK;
 }
 
-// The spill region holds (spill + 1) entries for every thread of the largest grid launched so far.
-int ensure_overflow(rt_scene* s, unsigned long long lanes) {
-    unsigned long long blocks = (lanes + kBlock - 1) / kBlock;
-    if (blocks < 256) blocks = 256;
-    if (blocks > (unsigned long long)kMaxGridBlocks) blocks = (unsigned long long)kMaxGridBlocks;
-    const uint32_t stride = (uint32_t)blocks * kBlock;
-    if (s->wk.overflow && s->wk.overflow_stride >= stride) return RT_OK;
-    if (s->wk.overflow) { (void)hipFree(s->wk.overflow); s->wk.overflow = nullptr; s->wk.overflow_stride = 0; }
-    HIP_TRY(hipMalloc((void**)&s->wk.overflow, (size_t)(s->spill + 1) * stride * sizeof(uint32_t)));
-    s->wk.overflow_stride = stride;
-    return RT_OK;
-}
-
-inline int grid_for(unsigned long long n) {
+inline int grid_for(unsigned long long n, int cap = kMaxGridBlocks) {
     unsigned long long b = (n + kBlock - 1) / kBlock;
     if (b < 1) b = 1;
-    return (int)(b < (unsigned long long)kMaxGridBlocks ? b : (unsigned long long)kMaxGridBlocks);
+    return (int)(b < (unsigned long long)cap ? b : (unsigned long long)cap);
 }
 
 }  // namespace
@@ -687,7 +863,7 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     *out = nullptr;
     if (desc->n_shapes < 0 || desc->n_materials < 0 || desc->n_textures < 0 || desc->n_lights < 0)
         return fail(RT_ERR_INVALID, "negative table size");
-    if (desc->n_shapes >= ((int64_t)1 << 28)) return fail(RT_ERR_LIMIT, "more than 2^28 shapes");
+    if (desc->n_shapes >= kMaxChildRecords) return fail(RT_ERR_LIMIT, "scene has " + std::to_string(desc->n_shapes) + " shapes; the limit is 2^24 - 1 (a leaf keeps 24 bits for its first shape)");
     if (desc->n_materials >= ((int64_t)1 << 30)) return fail(RT_ERR_LIMIT, "more than 2^30 materials");
     if ((desc->n_shapes > 0 && !desc->shapes) || (desc->n_materials > 0 && !desc->materials) ||
         (desc->n_textures > 0 && !desc->textures) || (desc->n_lights > 0 && !desc->lights))
@@ -853,7 +1029,8 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     s->d.materials = (const DMaterial*)s->d_mats; s->d.textures = (const DTexture*)s->d_texs;
     s->d.lights = (const DLight*)s->d_lights;
     s->d.n_lights = (int)desc->n_lights; s->d.n_pos_lights = n_pos; s->d.root_ref = flat.root_ref;
-    for (auto& e : s->ev) HIP_TRY_S(hipEventCreate(&e));
+    for (auto& e : s->ev_snap) HIP_TRY_S(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : s->ev_frame) HIP_TRY_S(hipEventCreate(&e));
     s->ev_ok = true;
 
     s->info.n_shapes = desc->n_shapes; s->info.n_inner_nodes = flat.n_inner;
@@ -871,13 +1048,15 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    free_work(s);
-    if (s->wk.overflow) (void)hipFree(s->wk.overflow);
+    (void)hipDeviceSynchronize();  // a call without stats may have left its tail on a stream
+    if (s->arena.owned && s->arena.base) (void)hipFree(s->arena.base);
     if (s->h_counters) (void)hipHostFree(s->h_counters);
     void* ptrs[] = {s->d_recs, s->d_qblocks, s->d_prims, s->d_tprims, s->d_prim_ids, s->d_mats, s->d_texs, s->d_lights};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : s->d_tex_pixels) (void)hipFree(p);
-    if (s->ev_ok) for (auto& e : s->ev) (void)hipEventDestroy(e);
+    for (DevBuf* b : {&s->accum, &s->rgba, &s->probe_in, &s->probe_out, &s->probe_out2}) b->release();
+    if (s->ev_ok) { for (auto& e : s->ev_snap) (void)hipEventDestroy(e); for (auto& e : s->ev_frame) (void)hipEventDestroy(e); }
+    for (auto& e : s->ev_pool) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -887,9 +1066,16 @@ int rt_scene_get_info(const rt_scene* s, rt_scene_info* out) {
     return RT_OK;
 }
 
-static int rt_render_accum_device_impl(rt_scene* s, const rt_image_spec* spec, const rt_partition* part_in,
-                           float* d_accum, void* hip_stream, rt_stats* stats) {
-    if (!s || !d_accum) return fail(RT_ERR_INVALID, "scene/accum is NULL");
+// What a render call needs besides the scene: its share of the frame, as batches of (pixel, sample) paths.
+struct RenderPlan {
+    rt_partition part;
+    int tile, tiles_x, sA, sB, ns_max, group, group_shift;
+    long long n_local_pixels, pix_per_batch;
+    int64_t batch_paths;
+    bool by_tiles, empty;
+};
+
+static int plan_render(const rt_scene* s, const rt_image_spec* spec, const rt_partition* part_in, int64_t paths_cap, RenderPlan* P) {
     int rc = validate_spec(spec);
     if (rc != RT_OK) return rc;
     rt_partition part{};
@@ -898,141 +1084,167 @@ static int rt_render_accum_device_impl(rt_scene* s, const rt_image_spec* spec, c
     if (part.mode < RT_PART_ALL || part.mode > RT_PART_SAMPLES) return fail(RT_ERR_INVALID, "unknown partition mode");
     if (part.mode == RT_PART_ALL) { part.rank = 0; part.world_size = 1; }
     if (part.world_size < 1 || part.rank < 0 || part.rank >= part.world_size) return fail(RT_ERR_INVALID, "bad rank/world_size");
-    int tile = part.tile_size > 0 ? part.tile_size : 64;
+    const int tile = part.tile_size > 0 ? part.tile_size : 64;
     if (tile % 8 != 0 || tile > 1024) return fail(RT_ERR_INVALID, "tile_size must be a multiple of 8, at most 1024");
-    HIP_TRY(hipSetDevice(s->device));
-    hipStream_t stream = (hipStream_t)hip_stream;
-
     const int W = spec->width, H = spec->height, D = spec->ray_tracing_max_depth;
     const int spp = spec->anti_aliasing_factor, reps = spec->soft_shadow_monte_carlo_repetitions;
-    const int tiles_x = (W + tile - 1) / tile, tiles_y = (H + tile - 1) / tile;
-    const long long n_tiles = (long long)tiles_x * tiles_y;
-    const bool by_tiles = part.mode == RT_PART_TILES;
-    const long long my_tiles = by_tiles ? (n_tiles - part.rank + part.world_size - 1) / part.world_size : n_tiles;
-    int sA = 0, sB = spp;
+    P->part = part; P->tile = tile;
+    P->tiles_x = (W + tile - 1) / tile;
+    const int tiles_y = (H + tile - 1) / tile;
+    const long long n_tiles = (long long)P->tiles_x * tiles_y;
+    P->by_tiles = part.mode == RT_PART_TILES;
+    const long long my_tiles = P->by_tiles ? (n_tiles - part.rank + part.world_size - 1) / part.world_size : n_tiles;
+    P->sA = 0; P->sB = spp;
     if (part.mode == RT_PART_SAMPLES) {
-        sA = (int)((long long)spp * part.rank / part.world_size);
-        sB = (int)((long long)spp * (part.rank + 1) / part.world_size);
+        P->sA = (int)((long long)spp * part.rank / part.world_size);
+        P->sB = (int)((long long)spp * (part.rank + 1) / part.world_size);
     }
+    P->n_local_pixels = my_tiles * tile * tile;
+    P->empty = !(P->sB > P->sA && D > 0 && P->n_local_pixels > 0);
+    P->ns_max = 1; P->pix_per_batch = (long long)tile * tile; P->batch_paths = 0;
+    // lanes per (hit, light) in the shadow kernel: smallest power of two >= min(reps, 64)
+    P->group = 1; P->group_shift = 0;
+    while (P->group < reps && P->group < 64) { P->group <<= 1; ++P->group_shift; }
+    if (P->empty) return RT_OK;
+    int64_t max_paths = part.max_paths_per_batch > 0 ? part.max_paths_per_batch : kDefaultMaxPaths;
+    if (paths_cap > 0 && max_paths > paths_cap) max_paths = paths_cap;
+    if (max_paths < (int64_t)tile * tile) {
+        if (paths_cap > 0) return fail(RT_ERR_LIMIT, "tile_size^2 paths do not fit the workspace of this entry point; use a smaller tile_size");
+        max_paths = (int64_t)tile * tile;
+    }
+    if (max_paths > ((int64_t)1 << 30)) max_paths = (int64_t)1 << 30;
+    // a (hit, light) pair travels as one u32: light * hits + hit
+    const int64_t pair_cap = (((int64_t)1 << 32) - 1) / std::max(1, s->d.n_pos_lights);
+    if (pair_cap < (int64_t)tile * tile) return fail(RT_ERR_LIMIT, "too many positional lights for one tile of paths; use a smaller tile_size");
+    if (max_paths > pair_cap) max_paths = pair_cap;
+    P->ns_max = (int)std::min<long long>(P->sB - P->sA, std::min<long long>(64, max_paths / ((long long)tile * tile)));
+    P->pix_per_batch = std::max<long long>(1, max_paths / P->ns_max / ((long long)tile * tile)) * tile * tile;
+    P->batch_paths = (int64_t)std::min<long long>(P->pix_per_batch, P->n_local_pixels) * P->ns_max;
+    return RT_OK;
+}
+
+// The wavefront loop over an arena that is already in place.  One host wait per bounce, on an event recorded right
+// after k_shade: it tells the host how long the next queue is while the device works on this bounce's shadow rays,
+// so the stream never drains inside a call.  Every kernel reads its queue length from device memory; the host's
+// numbers only size the grids (upper bounds: a queue never outgrows the one it came from).
+static int run_render(rt_scene* s, Arena& arena, const rt_image_spec* spec, const RenderPlan& P, float* d_accum, hipStream_t stream,
+                      rt_stats* stats, bool may_create_events) {
+    const int W = spec->width, H = spec->height, D = spec->ray_tracing_max_depth, reps = spec->soft_shadow_monte_carlo_repetitions;
+    const int L = s->d.n_pos_lights;
+    Work& wk = arena.wk;
     rt_stats st{};
     st.ms_build = s->ms_build;
-    const long long n_local_pixels = my_tiles * tile * tile;
-    if (sB > sA && D > 0 && n_local_pixels > 0) {
-        int64_t max_paths = part.max_paths_per_batch > 0 ? part.max_paths_per_batch : kDefaultMaxPaths;
-        if (max_paths < (int64_t)tile * tile) max_paths = (int64_t)tile * tile;
-        if (max_paths > ((int64_t)1 << 30)) max_paths = (int64_t)1 << 30;
-        // a (hit, light) pair travels as one u32: light * hits + hit
-        const int64_t pair_cap = (((int64_t)1 << 32) - 1) / std::max(1, s->d.n_pos_lights);
-        if (pair_cap < (int64_t)tile * tile) return fail(RT_ERR_LIMIT, "too many positional lights for one tile of paths; use a smaller tile_size");
-        if (max_paths > pair_cap) max_paths = pair_cap;
-        const int ns_max = (int)std::min<long long>(sB - sA, std::min<long long>(64, max_paths / ((long long)tile * tile)));
-        const long long pix_per_batch = std::max<long long>(1, max_paths / ns_max / ((long long)tile * tile)) * tile * tile;
-        const int64_t batch_paths = (int64_t)std::min<long long>(pix_per_batch, n_local_pixels) * ns_max;
-        rc = ensure_work(s, batch_paths, D, s->d.n_pos_lights);
-        if (rc != RT_OK) return rc;
-        // the widest launch is k_shadow's: one lane per (pair, repetition lane), at most 64 lanes per pair
-        rc = ensure_overflow(s, (unsigned long long)batch_paths * (unsigned long long)std::max(1, s->d.n_pos_lights) * 64ull);
-        if (rc != RT_OK) return rc;
-        Work& wk = s->wk;
-        // lanes per (hit, light) in the shadow kernel: smallest power of two >= min(reps, 64)
-        int group = 1, group_shift = 0;
-        while (group < reps && group < 64) { group <<= 1; ++group_shift; }
-
-        const bool timed = stats != nullptr;
-        hipEvent_t* ev = s->ev;
-        if (timed) HIP_TRY(hipEventRecord(ev[6], stream));
-        bool pend_shadow = false;
-        auto harvest_shadow = [&]() {
-            if (!pend_shadow) return;
-            float a = 0, b = 0;
-            (void)hipEventElapsedTime(&a, ev[3], ev[4]);
-            (void)hipEventElapsedTime(&b, ev[4], ev[5]);
-            st.ms_shadow += a; st.ms_shade += b;
-            pend_shadow = false;
-        };
-        const size_t n_ctr = (size_t)(3 * D + 8);
-        for (int s0 = sA; s0 < sB; s0 += ns_max) {
-            const int ns = std::min(ns_max, sB - s0);
-            for (long long lp0 = 0; lp0 < n_local_pixels; lp0 += pix_per_batch) {
-                Batch B{};
-                B.W = W; B.H = H; B.tile = tile; B.tiles_x = tiles_x;
-                B.rank = part.rank; B.world = part.world_size; B.by_tiles = by_tiles ? 1 : 0;
-                B.lp0 = lp0; B.npix = (int)std::min<long long>(pix_per_batch, n_local_pixels - lp0);
-                B.ns = ns; B.s0 = s0; B.max_depth = D; B.reps = reps;
-                B.k0 = (uint32_t)part.seed; B.k1 = (uint32_t)(part.seed >> 32);
-                const long long slots = (long long)B.npix * ns;
-                const DCamera cam = make_camera(s, W, H);
-                HIP_TRY(hipMemsetAsync(wk.counters, 0, n_ctr * sizeof(uint32_t), stream));
-                hipLaunchKernelGGL(k_raygen, dim3((unsigned)((slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, B, cam, wk);
-                HIP_TRY(hipMemcpyAsync(s->h_counters, wk.counters, n_ctr * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipStreamSynchronize(stream));
-                harvest_shadow();
-                uint32_t nq = s->h_counters[0];
-                st.paths += nq;
-                for (int b = 0; b < D && nq > 0; ++b) {
-                    uint32_t* q = wk.queue[b & 1];
-                    uint32_t* qn = wk.queue[(b + 1) & 1];
-                    if (timed) HIP_TRY(hipEventRecord(ev[0], stream));
-                    hipLaunchKernelGGL(k_extend, dim3(grid_for(nq)), dim3(kBlock), 0, stream, s->d, wk, q, nq);
-                    if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
-                    hipLaunchKernelGGL(k_shade, dim3((nq + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, B, wk, q, nq, qn, b);
-                    if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
-                    HIP_TRY(hipMemcpyAsync(s->h_counters, wk.counters, n_ctr * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                    HIP_TRY(hipStreamSynchronize(stream));
-                    harvest_shadow();
-                    if (timed) {
-                        float a = 0, c = 0;
-                        (void)hipEventElapsedTime(&a, ev[0], ev[1]);
-                        (void)hipEventElapsedTime(&c, ev[1], ev[2]);
-                        st.ms_extend += a; st.ms_shade += c;
-                    }
-                    if (b == 0) st.rays_primary += nq; else st.rays_continuation += nq;
-                    const uint32_t np = s->h_counters[D + 1 + b];
-                    nq = s->h_counters[b + 1];
-                    if (np > 0) {
-                        st.phong_hits += np;
-                        st.rays_shadow_reference_equivalent += (uint64_t)np * s->d.n_pos_lights * reps;
-                        if (s->d.n_pos_lights == 0 && timed) HIP_TRY(hipEventRecord(ev[3], stream));
-                        if (s->d.n_pos_lights > 0) {
-                            const unsigned long long n_pairs = (unsigned long long)np * s->d.n_pos_lights;
-                            uint32_t* pair_counter = wk.counters + 2 * D + 4 + b;
-                            const int L = s->d.n_pos_lights;
-                            HIP_TRY(hipMemsetAsync(wk.light_count, 0, (size_t)L * sizeof(uint32_t), stream));
-                            hipLaunchKernelGGL(k_phong_pairs, dim3((np + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, wk, np);
-                            hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(64), 0, stream, wk, L, pair_counter);
-                            hipLaunchKernelGGL(k_pair_compact, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, wk, np, L);
-                            if (timed) HIP_TRY(hipEventRecord(ev[3], stream));  // ms_shadow brackets k_shadow alone
-                            if (reps > 0) {
-                                const int grid = grid_for(n_pairs * group);  // upper bound; the kernel reads the real pair count
-                                hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(kBlock), 0, stream, s->d, B, wk, np, b, group, group_shift, pair_counter);
-                            }
-                        }
-                        if (timed) HIP_TRY(hipEventRecord(ev[4], stream));
-                        hipLaunchKernelGGL(k_phong, dim3((np + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, B, wk, np);
-                        if (timed) { HIP_TRY(hipEventRecord(ev[5], stream)); pend_shadow = true; }
+    const size_t n_ctr = (size_t)(3 * D + 8);
+    if (n_ctr > s->h_counter_words) return fail(RT_ERR_LIMIT, "RayTracingMaxDepth exceeds the counter snapshots of this scene");
+    const bool timed = stats != nullptr;
+    size_t ev_used = 0;
+    auto stamp = [&]() -> int {  // one timing event on the stream, from the pool (grown only where the entry point may allocate)
+        if (ev_used == s->ev_pool.size()) {
+            if (!may_create_events) return -1;
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return -1;
+            s->ev_pool.push_back(e);
+        }
+        if (hipEventRecord(s->ev_pool[ev_used], stream) != hipSuccess) return -1;
+        return (int)ev_used++;
+    };
+    struct Span { int a, b; int kind; };  // kind 0 = k_extend, 1 = k_shadow
+    std::vector<Span> spans;
+    if (timed) HIP_TRY(hipEventRecord(s->ev_frame[0], stream));
+    HIP_TRY(hipMemsetAsync(wk.frame_counters, 0, 4 * sizeof(unsigned long long), stream));
+    const DCamera cam = make_camera(s, W, H);
+    for (int s0 = P.sA; s0 < P.sB; s0 += P.ns_max) {
+        const int ns = std::min(P.ns_max, P.sB - s0);
+        for (long long lp0 = 0; lp0 < P.n_local_pixels; lp0 += P.pix_per_batch) {
+            Batch B{};
+            B.W = W; B.H = H; B.tile = P.tile; B.tiles_x = P.tiles_x;
+            B.rank = P.part.rank; B.world = P.part.world_size; B.by_tiles = P.by_tiles ? 1 : 0;
+            B.lp0 = lp0; B.npix = (int)std::min<long long>(P.pix_per_batch, P.n_local_pixels - lp0);
+            B.ns = ns; B.s0 = s0; B.max_depth = D; B.reps = reps;
+            B.k0 = (uint32_t)P.part.seed; B.k1 = (uint32_t)(P.part.seed >> 32);
+            const long long slots = (long long)B.npix * ns;
+            HIP_TRY(hipMemsetAsync(wk.counters, 0, n_ctr * sizeof(uint32_t), stream));
+            hipLaunchKernelGGL(k_raygen, dim3((unsigned)((slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, B, cam, wk);
+            uint32_t bound = (uint32_t)slots;  // >= the length of the queue of bounce b
+            for (int b = 0; b < D && bound > 0; ++b) {
+                uint32_t* q = wk.queue[b & 1];
+                uint32_t* qn = wk.queue[(b + 1) & 1];
+                const uint32_t* n_rays = wk.counters + b;
+                const uint32_t* n_phong = wk.counters + D + 1 + b;
+                Span se{-1, -1, 0}, ss{-1, -1, 1};
+                if (timed) se.a = stamp();
+                hipLaunchKernelGGL(k_extend, dim3(grid_for(bound, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, wk, q, n_rays);
+                if (timed) se.b = stamp();
+                hipLaunchKernelGGL(k_shade, dim3((bound + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, B, wk, q, n_rays, qn, b);
+                uint32_t* snap = s->h_counters + (size_t)(b & 1) * s->h_counter_words;
+                HIP_TRY(hipMemcpyAsync(snap, wk.counters, n_ctr * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipEventRecord(s->ev_snap[b & 1], stream));
+                // the PhongBlinn hits of this bounce (at most `bound`): pairs, shadow rays, shading
+                if (L > 0) {
+                    const unsigned long long n_pairs = (unsigned long long)bound * L;
+                    uint32_t* pair_counter = wk.counters + 2 * D + 4 + b;
+                    HIP_TRY(hipMemsetAsync(wk.light_count, 0, (size_t)L * sizeof(uint32_t), stream));
+                    hipLaunchKernelGGL(k_phong_pairs, dim3((bound + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, wk, n_phong);
+                    hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(64), 0, stream, wk, L, pair_counter);
+                    hipLaunchKernelGGL(k_pair_compact, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, wk, n_phong, L);
+                    if (reps > 0) {
+                        if (timed) ss.a = stamp();  // ms_shadow brackets k_shadow alone
+                        hipLaunchKernelGGL(k_shadow, dim3(grid_for(n_pairs * P.group, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, B, wk, n_phong, b,
+                                           P.group, P.group_shift, pair_counter);
+                        if (timed) ss.b = stamp();
                     }
                 }
-                hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((B.npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, B, wk, d_accum);
-                // shadow-ray counter of this batch (u64 at counters[2D+2])
-                HIP_TRY(hipMemcpyAsync(s->h_counters, wk.counters, n_ctr * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipStreamSynchronize(stream));
-                harvest_shadow();
-                unsigned long long sh = 0;
-                std::memcpy(&sh, s->h_counters + 2 * D + 2, 8);
-                st.rays_shadow += sh;
+                hipLaunchKernelGGL(k_phong, dim3((bound + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, B, wk, n_phong);
+                if (timed) { spans.push_back(se); spans.push_back(ss); }
+                // how long are this bounce's queues?  (the device is busy with the kernels above meanwhile)
+                HIP_TRY(hipEventSynchronize(s->ev_snap[b & 1]));
+                const uint32_t nq = snap[b], np = snap[D + 1 + b];
+                if (b == 0) { st.paths += nq; st.rays_primary += nq; } else st.rays_continuation += nq;
+                st.phong_hits += np;
+                st.rays_shadow_reference_equivalent += (uint64_t)np * L * reps;
+                bound = snap[b + 1];
             }
-        }
-        HIP_TRY(hipGetLastError());
-        if (timed) {
-            HIP_TRY(hipEventRecord(ev[7], stream));
-            HIP_TRY(hipEventSynchronize(ev[7]));
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, ev[6], ev[7]));
-            st.ms_render = ms;
+            hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((B.npix + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, B, wk, d_accum);
         }
     }
-    if (stats) *stats = st;
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        unsigned long long* fc = reinterpret_cast<unsigned long long*>(s->h_counters + 2 * s->h_counter_words);
+        HIP_TRY(hipMemcpyAsync(fc, wk.frame_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(s->ev_frame[1], stream));
+        HIP_TRY(hipEventSynchronize(s->ev_frame[1]));
+        st.rays_shadow = fc[0];
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_frame[0], s->ev_frame[1]));
+        st.ms_render = ms;
+        for (const Span& sp : spans) {
+            if (sp.a < 0 || sp.b < 0) continue;
+            float t = 0;
+            if (hipEventElapsedTime(&t, s->ev_pool[(size_t)sp.a], s->ev_pool[(size_t)sp.b]) != hipSuccess) continue;
+            (sp.kind == 0 ? st.ms_extend : st.ms_shadow) += t;
+        }
+        st.ms_shade = st.ms_render - st.ms_extend - st.ms_shadow;  // everything else between the first and the last launch
+        *stats = st;
+    }
     return RT_OK;
+}
+
+static int rt_render_accum_device_impl(rt_scene* s, const rt_image_spec* spec, const rt_partition* part_in,
+                           float* d_accum, void* hip_stream, rt_stats* stats) {
+    if (!s || !d_accum) return fail(RT_ERR_INVALID, "scene/accum is NULL");
+    RenderPlan P{};
+    int rc = plan_render(s, spec, part_in, 0, &P);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    if (P.empty) {
+        if (stats) { *stats = rt_stats{}; stats->ms_build = s->ms_build; }
+        return RT_OK;
+    }
+    // the widest launch is k_shadow's: one lane per (pair, repetition lane), at most 64 lanes per pair
+    rc = ensure_work(s, P.batch_paths, spec->ray_tracing_max_depth, s->d.n_pos_lights,
+                     (unsigned long long)P.batch_paths * (unsigned long long)std::max(1, s->d.n_pos_lights) * 64ull);
+    if (rc != RT_OK) return rc;
+    return run_render(s, s->arena, spec, P, d_accum, (hipStream_t)hip_stream, stats, true);
 }
 
 static int rt_resolve_device_impl(const float* d_accum, int32_t width, int32_t height, int32_t spp, uint8_t* d_rgba, void* hip_stream) {
@@ -1051,16 +1263,12 @@ static int rt_render_accum_impl(rt_scene* s, const rt_image_spec* spec, const rt
     if (rc != RT_OK) return rc;
     HIP_TRY(hipSetDevice(s->device));
     const size_t bytes = (size_t)spec->width * spec->height * 3 * sizeof(float);
-    float* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, bytes));
-    hipError_t e = hipMemset(d, 0, bytes);
-    rc = e == hipSuccess ? rt_render_accum_device(s, spec, part, d, nullptr, stats) : fail(RT_ERR_DEVICE, hipGetErrorString(e));
-    if (rc == RT_OK) {
-        e = hipMemcpy(accum_out, d, bytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, hipGetErrorString(e));
-    }
-    (void)hipFree(d);
-    return rc;
+    HIP_TRY(s->accum.ensure(bytes));  // kept by the scene: no allocation per frame
+    HIP_TRY(hipMemsetAsync(s->accum.p, 0, bytes, nullptr));
+    rc = rt_render_accum_device(s, spec, part, (float*)s->accum.p, nullptr, stats);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipMemcpy(accum_out, s->accum.p, bytes, hipMemcpyDeviceToHost));
+    return RT_OK;
 }
 
 static int rt_render_impl(rt_scene* s, const rt_image_spec* spec, const rt_partition* part, uint8_t* rgba_out, rt_stats* stats) {
@@ -1069,21 +1277,14 @@ static int rt_render_impl(rt_scene* s, const rt_image_spec* spec, const rt_parti
     if (rc != RT_OK) return rc;
     HIP_TRY(hipSetDevice(s->device));
     const size_t npx = (size_t)spec->width * spec->height;
-    float* d = nullptr;
-    uint8_t* d8 = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, npx * 3 * sizeof(float)));
-    hipError_t e = hipMalloc((void**)&d8, npx * 4);
-    if (e != hipSuccess) { (void)hipFree(d); return fail(RT_ERR_DEVICE, hipGetErrorString(e)); }
-    e = hipMemset(d, 0, npx * 3 * sizeof(float));
-    rc = e == hipSuccess ? rt_render_accum_device(s, spec, part, d, nullptr, stats) : fail(RT_ERR_DEVICE, hipGetErrorString(e));
-    if (rc == RT_OK) rc = rt_resolve_device(d, spec->width, spec->height, spec->anti_aliasing_factor, d8, nullptr);
-    if (rc == RT_OK) {
-        e = hipMemcpy(rgba_out, d8, npx * 4, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(RT_ERR_DEVICE, hipGetErrorString(e));
-    }
-    (void)hipFree(d);
-    (void)hipFree(d8);
-    return rc;
+    HIP_TRY(s->accum.ensure(npx * 3 * sizeof(float)));
+    HIP_TRY(s->rgba.ensure(npx * 4));
+    HIP_TRY(hipMemsetAsync(s->accum.p, 0, npx * 3 * sizeof(float), nullptr));
+    rc = rt_render_accum_device(s, spec, part, (float*)s->accum.p, nullptr, stats);
+    if (rc == RT_OK) rc = rt_resolve_device((const float*)s->accum.p, spec->width, spec->height, spec->anti_aliasing_factor, (uint8_t*)s->rgba.p, nullptr);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipMemcpy(rgba_out, s->rgba.p, npx * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
 }
 
 static int rt_generate_image_impl(const rt_scene_desc* desc, const rt_image_spec* spec, const rt_partition* part, uint8_t* rgba_out, rt_stats* stats) {
@@ -1102,21 +1303,17 @@ static int rt_trace_rays_impl(rt_scene* s, const float* rays, int64_t n, int32_t
     if (n == 0) return RT_OK;
     if (n > ((int64_t)1 << 30)) return fail(RT_ERR_LIMIT, "more than 2^30 rays in one call");
     HIP_TRY(hipSetDevice(s->device));
-    float* d_rays = nullptr; int* d_prim = nullptr; float* d_t = nullptr;
     int rc = ensure_overflow(s, (unsigned long long)n);
     if (rc != RT_OK) return rc;
-    HIP_TRY(hipMalloc((void**)&d_rays, (size_t)n * 8 * sizeof(float)));
-    hipError_t e = hipMalloc((void**)&d_prim, (size_t)n * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_t, (size_t)n * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_trace_probe, dim3(grid_for((unsigned long long)n)), dim3(kBlock), 0, nullptr, s->d, s->wk, d_rays, (uint32_t)n, any_hit, d_prim, d_t);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpy(prim_out, d_prim, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(t_out, d_t, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
-    (void)hipFree(d_rays); (void)hipFree(d_prim); (void)hipFree(d_t);
-    if (e != hipSuccess) return fail(RT_ERR_DEVICE, hipGetErrorString(e));
+    HIP_TRY(s->probe_in.ensure((size_t)n * 8 * sizeof(float)));
+    HIP_TRY(s->probe_out.ensure((size_t)n * sizeof(int)));
+    HIP_TRY(s->probe_out2.ensure((size_t)n * sizeof(float)));
+    HIP_TRY(hipMemcpy(s->probe_in.p, rays, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_trace_probe, dim3(grid_for((unsigned long long)n, s->arena.grid_cap)), dim3(kBlock), 0, nullptr, s->d, s->arena.wk,
+                       (const float*)s->probe_in.p, (uint32_t)n, any_hit, (int*)s->probe_out.p, (float*)s->probe_out2.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(prim_out, s->probe_out.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t_out, s->probe_out2.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -1125,20 +1322,39 @@ static int rt_camera_rays_impl(rt_scene* s, const rt_image_spec* spec, uint64_t 
     int rc = validate_spec(spec);
     if (rc != RT_OK) return rc;
     if (n == 0) return RT_OK;
+    if (n > ((int64_t)1 << 30)) return fail(RT_ERR_LIMIT, "more than 2^30 rays in one call");
     HIP_TRY(hipSetDevice(s->device));
-    int* d_px = nullptr; float* d_out = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_px, (size_t)n * 3 * sizeof(int)));
-    hipError_t e = hipMalloc((void**)&d_out, (size_t)n * 6 * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpy(d_px, pixels, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        const DCamera cam = make_camera(s, spec->width, spec->height);
-        hipLaunchKernelGGL(k_camera_probe, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, cam, spec->width, spec->height,
-                           (uint32_t)seed, (uint32_t)(seed >> 32), d_px, (uint32_t)n, d_out);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpy(rays_out, d_out, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost);
-    (void)hipFree(d_px); (void)hipFree(d_out);
-    if (e != hipSuccess) return fail(RT_ERR_DEVICE, hipGetErrorString(e));
+    HIP_TRY(s->probe_in.ensure((size_t)n * 3 * sizeof(int)));
+    HIP_TRY(s->probe_out.ensure((size_t)n * 6 * sizeof(float)));
+    HIP_TRY(hipMemcpy(s->probe_in.p, pixels, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice));
+    const DCamera cam = make_camera(s, spec->width, spec->height);
+    hipLaunchKernelGGL(k_camera_probe, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, nullptr, cam, spec->width, spec->height,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), (const int*)s->probe_in.p, (uint32_t)n, (float*)s->probe_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(rays_out, s->probe_out.p, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+static int rt_scatter_probe_impl(rt_scene* s, const rt_image_spec* spec, uint64_t seed, const float* rays, const uint32_t* keys, int64_t n, float* out) {
+    if (!s || !rays || !keys || !out || n < 0) return fail(RT_ERR_INVALID, "bad scatter-probe arguments");
+    int rc = validate_spec(spec);
+    if (rc != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    if (n > ((int64_t)1 << 24)) return fail(RT_ERR_LIMIT, "more than 2^24 probes in one call");
+    HIP_TRY(hipSetDevice(s->device));
+    rc = ensure_overflow(s, (unsigned long long)n);
+    if (rc != RT_OK) return rc;
+    const size_t ray_bytes = (size_t)n * 6 * sizeof(float), key_bytes = (size_t)n * 3 * sizeof(uint32_t);
+    HIP_TRY(s->probe_in.ensure(align_up(ray_bytes) + key_bytes));
+    HIP_TRY(s->probe_out.ensure((size_t)n * 20 * sizeof(float)));
+    unsigned char* in = (unsigned char*)s->probe_in.p;
+    HIP_TRY(hipMemcpy(in, rays, ray_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(in + align_up(ray_bytes), keys, key_bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_scatter_probe, dim3(grid_for((unsigned long long)n, s->arena.grid_cap)), dim3(kBlock), 0, nullptr, s->d, s->arena.wk,
+                       (const float*)in, (const uint32_t*)(in + align_up(ray_bytes)), (uint32_t)n, (uint32_t)seed, (uint32_t)(seed >> 32),
+                       spec->soft_shadow_monte_carlo_repetitions, (float*)s->probe_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, s->probe_out.p, (size_t)n * 20 * sizeof(float), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -1179,6 +1395,9 @@ int rt_trace_rays(rt_scene* s, const float* rays, int64_t n, int32_t any_hit, in
 }
 int rt_camera_rays(rt_scene* s, const rt_image_spec* spec, uint64_t seed, const int32_t* pixels, int64_t n, float* rays_out) {
     return guarded([&] { return rt_camera_rays_impl(s, spec, seed, pixels, n, rays_out); });
+}
+int rt_scatter_probe(rt_scene* s, const rt_image_spec* spec, uint64_t seed, const float* rays, const uint32_t* keys, int64_t n, float* out) {
+    return guarded([&] { return rt_scatter_probe_impl(s, spec, seed, rays, keys, n, out); });
 }
 
 }  // extern "C"

@@ -224,6 +224,11 @@ def config5(width=3840, height=2160, spp=64, reps=16, asset_dir=None, nu=660, nv
     back = PhongBlinn(ColorFrac=Vec(0.7, 0.7, 0.7), SpecularColorFrac=Vec(0.1, 0.1, 0.1), SpecHardness=4,
                       Texture=_tile_texture(asset_dir))
     shapes = _room(mats=(metal, wall, back, wall, wall))
+    # Metal.scatter starts the reflected ray AT the hit point (material.go:49, no epsilon): a two-sided mirror
+    # triangle is then hit again at t = +-rounding noise.  The reference's own mirrors are SingleSided for that
+    # reason (example.go:141-152), and so is this floor: a ray leaving it sees its back face.
+    for tri in shapes[:2]:
+        tri.SingleSided = True
     glass = Dielectric(RefractiveIndex=1.52)
     for k in range(6):
         a = 2 * math.pi * k / 6
