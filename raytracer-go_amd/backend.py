@@ -15,7 +15,8 @@ LIB_PATH = os.path.join(_CSRC, "librtgo_hip.so")
 # every extern "C" symbol include/rtgo.h declares
 SYMBOLS = ("rt_last_error", "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info",
            "rt_render", "rt_render_accum_device", "rt_render_accum", "rt_resolve_device",
-           "rt_generate_image", "rt_trace_rays", "rt_camera_rays", "rt_scatter_probe")
+           "rt_generate_image", "rt_trace_rays", "rt_camera_rays", "rt_scatter_probe",
+           "rt_render_accum_device_static")
 
 
 class RtgoError(RuntimeError):
@@ -53,6 +54,7 @@ def lib():
         L.rt_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_render_accum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_render_accum_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_render_accum_device_static.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_resolve_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.rt_generate_image.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
@@ -127,6 +129,15 @@ class DeviceScene:
         st = _abi.RtStats()
         _check(lib().rt_render_accum_device(self._h, C.addressof(s), C.addressof(p), C.c_void_p(accum_ptr),
                                             C.c_void_p(stream or 0), C.addressof(st) if want_stats else None))
+        return st
+
+    def render_accum_device_static(self, spec, accum_ptr, stream=None, seed=0x5EED, part=None, want_stats=True):
+        """render_accum_device through the entry point that allocates nothing (static 72 MiB workspace per GPU)."""
+        s = _abi.image_spec(spec)
+        p = part if part is not None else _abi.partition(seed=seed)
+        st = _abi.RtStats()
+        _check(lib().rt_render_accum_device_static(self._h, C.addressof(s), C.addressof(p), C.c_void_p(accum_ptr),
+                                                   C.c_void_p(stream or 0), C.addressof(st) if want_stats else None))
         return st
 
     def trace_rays(self, rays, any_hit=False):

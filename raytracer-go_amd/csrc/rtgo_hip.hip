@@ -19,6 +19,7 @@
 #include <thread>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -694,6 +695,23 @@ struct rt_scene {
     DevBuf accum, rgba, probe_in, probe_out, probe_out2;
 };
 
+// ---- workspace of rt_render_accum_device_static, the entry point that allocates nothing ------------------------
+// A file-scope device array: the loader places one copy on every GPU the library runs on, at an address of its
+// own there; it is held until the process ends.  In host code the NAME below is only a stand-in for the symbol:
+// the memory is reached through the pointer hipGetSymbolAddress() gives for the current device (rt_init), never
+// through the name.
+constexpr int64_t kStaticPaths = (int64_t)1 << 18;  // (pixel, sample) paths of one batch
+constexpr int kStaticLights = 4;                    // positional lights
+constexpr int kStaticDepth = 64;                    // RayTracingMaxDepth
+constexpr int kStaticSpill = 32;                    // traversal-stack entries per lane beyond the LDS part
+constexpr int kStaticGrid = 1024;                   // blocks of a grid-stride launch (the spill region is per thread of it)
+constexpr size_t kScratchBytes = (size_t)72 << 20;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static unsigned char* g_scratch_ptr[kMaxDevices] = {};  // per device: where `scratch` lives there
+
 namespace {
 
 constexpr size_t kAlign = 256;
@@ -855,6 +873,14 @@ int rt_init(int device) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(RT_ERR_DEVICE, std::string("librtgo_hip is built for gfx950 only, found ") + prop.gcnArchName);
+    if (device < kMaxDevices) {  // once per device, with that device current: this GPU's copy of the static workspace
+        std::lock_guard<std::mutex> g(g_scratch_mutex);
+        if (!g_scratch_ptr[device]) {
+            unsigned char* ptr = nullptr;
+            HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+            g_scratch_ptr[device] = ptr;
+        }
+    }
     return RT_OK;
 }
 
@@ -1029,6 +1055,8 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     s->d.materials = (const DMaterial*)s->d_mats; s->d.textures = (const DTexture*)s->d_texs;
     s->d.lights = (const DLight*)s->d_lights;
     s->d.n_lights = (int)desc->n_lights; s->d.n_pos_lights = n_pos; s->d.root_ref = flat.root_ref;
+    s->h_counter_words = (size_t)(3 * kStaticDepth + 8);
+    HIP_TRY_S(hipHostMalloc((void**)&s->h_counters, kSnapshots * s->h_counter_words * sizeof(uint32_t)));
     for (auto& e : s->ev_snap) HIP_TRY_S(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : s->ev_frame) HIP_TRY_S(hipEventCreate(&e));
     s->ev_ok = true;
@@ -1137,6 +1165,7 @@ static int run_render(rt_scene* s, Arena& arena, const rt_image_spec* spec, cons
     const size_t n_ctr = (size_t)(3 * D + 8);
     if (n_ctr > s->h_counter_words) return fail(RT_ERR_LIMIT, "RayTracingMaxDepth exceeds the counter snapshots of this scene");
     const bool timed = stats != nullptr;
+    const bool staged = timed && may_create_events;  // per-stage events (and their host-side list) only where the entry point may allocate
     size_t ev_used = 0;
     auto stamp = [&]() -> int {  // one timing event on the stream, from the pool (grown only where the entry point may allocate)
         if (ev_used == s->ev_pool.size()) {
@@ -1172,9 +1201,9 @@ static int run_render(rt_scene* s, Arena& arena, const rt_image_spec* spec, cons
                 const uint32_t* n_rays = wk.counters + b;
                 const uint32_t* n_phong = wk.counters + D + 1 + b;
                 Span se{-1, -1, 0}, ss{-1, -1, 1};
-                if (timed) se.a = stamp();
+                if (staged) se.a = stamp();
                 hipLaunchKernelGGL(k_extend, dim3(grid_for(bound, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, wk, q, n_rays);
-                if (timed) se.b = stamp();
+                if (staged) se.b = stamp();
                 hipLaunchKernelGGL(k_shade, dim3((bound + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, B, wk, q, n_rays, qn, b);
                 uint32_t* snap = s->h_counters + (size_t)(b & 1) * s->h_counter_words;
                 HIP_TRY(hipMemcpyAsync(snap, wk.counters, n_ctr * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -1188,14 +1217,14 @@ static int run_render(rt_scene* s, Arena& arena, const rt_image_spec* spec, cons
                     hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(64), 0, stream, wk, L, pair_counter);
                     hipLaunchKernelGGL(k_pair_compact, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, wk, n_phong, L);
                     if (reps > 0) {
-                        if (timed) ss.a = stamp();  // ms_shadow brackets k_shadow alone
+                        if (staged) ss.a = stamp();  // ms_shadow brackets k_shadow alone
                         hipLaunchKernelGGL(k_shadow, dim3(grid_for(n_pairs * P.group, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, B, wk, n_phong, b,
                                            P.group, P.group_shift, pair_counter);
-                        if (timed) ss.b = stamp();
+                        if (staged) ss.b = stamp();
                     }
                 }
                 hipLaunchKernelGGL(k_phong, dim3((bound + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, B, wk, n_phong);
-                if (timed) { spans.push_back(se); spans.push_back(ss); }
+                if (staged) { spans.push_back(se); spans.push_back(ss); }
                 // how long are this bounce's queues?  (the device is busy with the kernels above meanwhile)
                 HIP_TRY(hipEventSynchronize(s->ev_snap[b & 1]));
                 const uint32_t nq = snap[b], np = snap[D + 1 + b];
@@ -1245,6 +1274,40 @@ static int rt_render_accum_device_impl(rt_scene* s, const rt_image_spec* spec, c
                      (unsigned long long)P.batch_paths * (unsigned long long)std::max(1, s->d.n_pos_lights) * 64ull);
     if (rc != RT_OK) return rc;
     return run_render(s, s->arena, spec, P, d_accum, (hipStream_t)hip_stream, stats, true);
+}
+
+// rt_render_accum_device for callers that cannot allocate: the batch workspace is this GPU's copy of `scratch`.
+static int rt_render_accum_device_static_impl(rt_scene* s, const rt_image_spec* spec, const rt_partition* part_in,
+                                              float* d_accum, void* hip_stream, rt_stats* stats) {
+    if (!s || !d_accum) return fail(RT_ERR_INVALID, "scene/accum is NULL");
+    RenderPlan P{};
+    int rc = plan_render(s, spec, part_in, kStaticPaths, &P);
+    if (rc != RT_OK) return rc;
+    const int D = spec->ray_tracing_max_depth, L = s->d.n_pos_lights;
+    if (D > kStaticDepth) return fail(RT_ERR_LIMIT, "rt_render_accum_device_static: RayTracingMaxDepth > 64");
+    if (L > kStaticLights) return fail(RT_ERR_LIMIT, "rt_render_accum_device_static: more than 4 positional lights");
+    if (s->spill + 1 > kStaticSpill)
+        return fail(RT_ERR_LIMIT, "rt_render_accum_device_static: the scene's tree can need " + std::to_string(s->info.stack_bound + 1) +
+                                      " traversal-stack entries per ray; the static workspace holds " + std::to_string(kLdsStackDepth + kStaticSpill - 1));
+    if (s->device >= kMaxDevices || !g_scratch_ptr[s->device]) return fail(RT_ERR_DEVICE, "no static workspace on this device");
+    HIP_TRY(hipSetDevice(s->device));
+    if (P.empty) {
+        if (stats) { *stats = rt_stats{}; stats->ms_build = s->ms_build; }
+        return RT_OK;
+    }
+    Arena st;
+    st.owned = false;
+    st.base = g_scratch_ptr[s->device];  // the device address, not the symbol's name
+    st.bytes = kScratchBytes;
+    st.grid_cap = kStaticGrid;
+    const unsigned long long entries = s->spill > 0 ? (unsigned long long)(s->spill + 1) * kStaticGrid * kBlock : 0ull;
+    const size_t need = carve_work(&st.wk, st.base, P.batch_paths, D, L, entries);
+    if (need > kScratchBytes) return fail(RT_ERR_LIMIT, "rt_render_accum_device_static: the batch does not fit the 72 MiB static workspace");
+    st.wk.overflow_stride = (uint32_t)kStaticGrid * kBlock;
+    st.paths = P.batch_paths; st.depth = D; st.lpos = L; st.overflow_entries = entries;
+    // nothing in the workspace has to survive from an earlier call: run_render zeroes the counters it reads, and
+    // every other array is written before it is read
+    return run_render(s, st, spec, P, d_accum, (hipStream_t)hip_stream, stats, false);
 }
 
 static int rt_resolve_device_impl(const float* d_accum, int32_t width, int32_t height, int32_t spp, uint8_t* d_rgba, void* hip_stream) {
@@ -1377,6 +1440,9 @@ int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out) {
 }
 int rt_render_accum_device(rt_scene* s, const rt_image_spec* spec, const rt_partition* part_in, float* d_accum, void* hip_stream, rt_stats* stats) {
     return guarded([&] { return rt_render_accum_device_impl(s, spec, part_in, d_accum, hip_stream, stats); });
+}
+int rt_render_accum_device_static(rt_scene* s, const rt_image_spec* spec, const rt_partition* part_in, float* d_accum, void* hip_stream, rt_stats* stats) {
+    return guarded([&] { return rt_render_accum_device_static_impl(s, spec, part_in, d_accum, hip_stream, stats); });
 }
 int rt_resolve_device(const float* d_accum, int32_t width, int32_t height, int32_t spp, uint8_t* d_rgba, void* hip_stream) {
     return guarded([&] { return rt_resolve_device_impl(d_accum, width, height, spp, d_rgba, hip_stream); });
