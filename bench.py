@@ -12,6 +12,8 @@ A step = one whole frame.  At N > 1 the frame's samples are split over the ranks
 reduce(sum) lands the frame on rank 0, which divides and quantises: total work is fixed, so
 "scaling" is "strong".  value = rays traced by all ranks / wall time of the timed region (scene
 already resident in HBM; the timed region ends with the RGBA8 frame in device memory on rank 0).
+sec_per_frame_one_shot is what the reference's own clock covers (raytracer.go:69-105): tree build +
+upload + the first frame.
 """
 import argparse
 import importlib
@@ -22,8 +24,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-GOLD = os.path.join(ROOT, "tests", "golden")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+BOUNDS = os.path.join(ROOT, "profiles", "r02", "bounds.json")  # per-frame counter totals of k_shadow + calibrated unit rates
 
 
 def main():
@@ -38,9 +40,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=480, help="rows of the 1-spp slice the CPU baseline renders")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
-    import torch.distributed as dist
 
     rt = importlib.import_module("raytracer-go_amd")
     abi = rt._abi
@@ -64,92 +64,47 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend_name = os.environ.get("RTGO_DIST_BACKEND", "nccl" if n_dev >= world else "gloo")
-        if backend_name == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend_name, rank=rank, world_size=world)
+        rtdist.init_process_group(rank, world, rtdist.pick_backend(world, n_dev), dev)
 
-    spec, scene = scenes.config3(args.width, args.height, args.spp, 16, asset_dir=GOLD)
-    dscene = backend.DeviceScene(scene, device=local_rank)
+    t_cold = time.perf_counter()
+    spec, scene = scenes.config3(args.width, args.height, args.spp, 16)
+    t_scene = time.perf_counter()
+    dscene = backend.DeviceScene(scene, device=local_rank)  # = NewBoundingVolumeHierarchy + upload (raytracer.go:69)
     info = dscene.info()
     W, H = spec.Width, spec.Height
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    totals = {"rays": 0, "primary": 0, "continuation": 0, "shadow": 0, "shadow_ref_eq": 0,
-              "ms_extend": 0.0, "ms_shadow": 0.0, "ms_shade": 0.0}
+    keys = ("rays", "rays_primary", "rays_continuation", "rays_shadow", "rays_shadow_reference_equivalent",
+            "ms_extend", "ms_shadow", "ms_shade")
 
-    def step(record):
-        accum.zero_()
+    def share(part):
+        st = dscene.render_accum_device(spec, accum.data_ptr(), stream=stream, part=part)
+        return {k: float(getattr(st, k)) for k in keys}
 
-        def share(part):
-            st = dscene.render_accum_device(spec, accum.data_ptr(), stream=stream, part=part)
-            if record:
-                totals["rays"] += st.rays
-                totals["primary"] += st.rays_primary
-                totals["continuation"] += st.rays_continuation
-                totals["shadow"] += st.rays_shadow
-                totals["shadow_ref_eq"] += st.rays_shadow_reference_equivalent
-                totals["ms_extend"] += st.ms_extend
-                totals["ms_shadow"] += st.ms_shadow
-                totals["ms_shade"] += st.ms_shade
-
-        rtdist.render_frame(share, accum, spec, abi.RT_PART_SAMPLES, rank, world,
-                            reduce_fn=(lambda a: dist.reduce(a, dst=0, op=dist.ReduceOp.SUM)) if world > 1 else None)
-        if rank == 0:
-            backend.resolve_device(accum.data_ptr(), W, H, spec.AntiAliasingFactor, rgba.data_ptr(), stream=stream)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step(False)
-    fence()
+    loop = rtdist.FrameLoop(spec, abi.RT_PART_SAMPLES, rank, world, accum, share,
+                            resolve=lambda a: backend.resolve_device(a.data_ptr(), W, H, spec.AntiAliasingFactor, rgba.data_ptr(), stream=stream))
+    # the first frame, cold: with the tree build and the upload before it, this is one GenerateImage call
+    loop.step()
+    loop.fence()
+    one_shot = time.perf_counter() - t_scene
+    for _ in range(max(0, args.warmup - 1)):
+        loop.step()
+    loop.fence()
+    totals = dict.fromkeys(keys, 0.0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
-    fence()
-    elapsed = time.perf_counter() - t0
-
-    agg = torch.tensor([elapsed] + [float(totals[k]) for k in ("rays", "primary", "continuation", "shadow", "shadow_ref_eq",
-                                                               "ms_extend", "ms_shadow", "ms_shade")],
-                       dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = agg[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        agg[0] = tmax[0]
-    agg = agg.cpu().numpy()
-    elapsed = float(agg[0])
-    rays, n_prim, n_cont, n_shadow, n_shadow_ref, ms_extend, ms_shadow, ms_shade = [float(x) for x in agg[1:]]
+        for k, v in loop.step().items():
+            totals[k] += v
+    loop.fence()
+    elapsed, sums = loop.aggregate(time.perf_counter() - t0, [totals[k] for k in keys] + [one_shot])
+    rays, n_prim, n_cont, n_shadow, n_shadow_ref, ms_extend, ms_shadow, ms_shade, one_shot_sum = sums
 
     if rank == 0:
-        with open(os.path.join(GOLD, "bray.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "bray.json")) as f:
             bray_all = json.load(f)
-            bray = bray_all["config3"]
-        # dominant kernel: k_shadow (any-hit traversal of the soft-shadow rays)
-        shadow_bytes = n_shadow * bray["shadow"]["bytes_per_ray"]
-        shadow_s = ms_shadow / 1e3 / world  # mean over ranks of the kernel's summed launch durations
-        achieved = shadow_bytes / world / shadow_s / 1e9 if shadow_s > 0 else 0.0
-        extend_bytes = n_prim * bray["primary"]["bytes_per_ray"] + n_cont * bray["continuation"]["bytes_per_ray"]
-        traffic = None  # HBM-side bytes per k_shadow launch, from the committed rocprofv3 PMC passes of this same workload
-        issue = None    # the same passes' VALU figures: what actually bounds the kernel
-        tpath = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            if world == 1 and tj["workload"] == {"width": W, "height": H, "spp": spec.AntiAliasingFactor, "config": "config3"}:  # per-launch figures of the 1-GPU run
-                traffic = tj["hbm_bytes_per_launch"]
-                isu = tj.get("issue")
-                if isu and shadow_s > 0 and world == 1:
-                    issue = {"valu_insts_per_ray": isu["valu_insts_per_frame"] / (n_shadow / args.steps),
-                             "valu_active_lane_frac": isu["valu_active_lane_frac"],
-                             "valu_busy_frac_profiled": isu["valu_busy_seconds_per_frame"] / (shadow_s / args.steps),
-                             "source": "profiles/r01/m_final_pmc.txt"}
+        bray = bray_all["config3"]
+        shadow_s = ms_shadow / 1e3 / world / args.steps  # k_shadow seconds per frame (mean over ranks of the summed launch durations)
         out = {
             "metric": "Mrays/s (whole node), Stanford Dragon 1080p 64spp",
             "value": rays / elapsed / 1e6,
@@ -157,6 +112,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "sec_per_frame": elapsed / args.steps,
+            "sec_per_frame_one_shot": one_shot_sum / world,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "config3: Dragon stand-in (seeded torus-knot tube, 871,200 tris) in 10-tri room, "
@@ -169,19 +125,64 @@ def main():
                                "shadow": n_shadow / args.steps, "shadow_reference_equivalent": n_shadow_ref / args.steps},
             "kernel_ms_per_frame": {"k_extend": ms_extend / args.steps / world, "k_shadow": ms_shadow / args.steps / world,
                                     "shade_phong_other": ms_shade / args.steps / world},
-            "roofline": {"bound": "hbm", "kernel": "k_shadow", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_ray": bray["shadow"]["bytes_per_ray"], "issue_bound": issue,
-                         # the same rate priced with what THIS tree reads per ray (fewer, fuller blocks than the reference's octree)
-                         "achieved_device_tree": achieved * bray_all["config3_device_tree"]["bytes_per_ray"] / bray["shadow"]["bytes_per_ray"],
-                         "k_extend_achieved": (extend_bytes / world / (ms_extend / 1e3 / world) / 1e9) if ms_extend > 0 else 0.0},
+            "roofline": roofline(shadow_s, n_shadow / args.steps / world, world, W, H, spec.AntiAliasingFactor, bray),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, spec, args.cpu_rows)
         print(json.dumps(out), flush=True)
     dscene.close()
     if world > 1:
+        import torch.distributed as dist
+
         dist.destroy_process_group()
+
+
+def roofline(shadow_s, shadow_rays, world, W, H, spp, bray):
+    """Which unit of the chip k_shadow keeps busiest, as a fraction of what that unit sustains.
+
+    The kernel's tree and shapes (~60 MB) stay in L2 / Infinity Cache, so HBM is not its roof (hbm_frac below).
+    The candidates are VALU issue and the vector-memory path (TA + vector L1).  Their per-frame work is counted by
+    rocprofv3 PMC passes over this same command (profiles/r02/bounds.json: instruction and access counts are
+    properties of the workload, identical from run to run for a seed); what each unit sustains per clock comes
+    from the micro-benchmarks of scripts/calib.hip run on the same box (same file).  frac = busy time of the
+    busiest unit / the kernel's measured time (HIP events around every k_shadow launch of the timed region)."""
+    out = {"bound": None, "kernel": "k_shadow", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+           "kernel_s_per_frame": shadow_s}
+    # SURVEY 8d's figure, kept for the record: the REFERENCE's traversal bytes (its octree, 224 B per node) per second
+    out["reference_equivalent_GBps"] = shadow_rays * bray["shadow"]["bytes_per_ray"] / shadow_s / 1e9 if shadow_s > 0 else None
+    if not os.path.exists(BOUNDS) or shadow_s <= 0:
+        return out
+    with open(BOUNDS) as f:
+        b = json.load(f)
+    if world != 1 or b["workload"] != {"width": W, "height": H, "spp": spp, "config": "config3"}:
+        return out  # the committed counts are per frame of the 1-GPU headline run
+    pf, c = b["per_frame"], b["calib"]
+    clk = c["clock_hz"]
+    valu_s = pf["valu_insts"] * c["valu_cycles_per_wave_inst_per_simd"] / (c["simds"] * clk)
+    hits = pf["tcp_accesses"] - pf["tcp_l2_read_req"]
+    ta_s = (hits / c["tcp_l1_hit_accesses_per_clk_per_cu"] + pf["tcp_l2_read_req"] / c["tcp_l2_served_accesses_per_clk_per_cu"]) / (c["cus"] * clk)
+    hbm_bytes = 2 * pf["hbm_fetch_bytes"] + pf["hbm_write_bytes"]  # gfx950 FETCH_SIZE counts half the bytes (guide, HBM section)
+    fr = {"valu_issue": valu_s / shadow_s, "ta_l1": ta_s / shadow_s, "hbm": hbm_bytes / shadow_s / (HBM_PEAK_GBS * 1e9)}
+    bound = max(fr, key=fr.get)
+    if bound == "valu_issue":
+        out.update(achieved=pf["valu_insts"] / shadow_s / 1e9, peak=c["simds"] * clk / c["valu_cycles_per_wave_inst_per_simd"] / 1e9, unit="G wave64-inst/s")
+    elif bound == "ta_l1":
+        out.update(achieved=pf["tcp_accesses"] / shadow_s / 1e9, peak=pf["tcp_accesses"] / ta_s / 1e9, unit="G L1-access/s")
+    else:
+        out.update(achieved=hbm_bytes / shadow_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+    out.update(bound=bound, frac=fr[bound], traffic=hbm_bytes / b["launches_per_frame"], fractions=fr,
+               ta_busy_frac_profiled=pf.get("ta_busy_frac"), source="profiles/r02/bounds.json")
+    return out
+
+
+def cpu_threads():
+    """The host threads this process may use: its CPU affinity, capped by OMP_NUM_THREADS where the box sets a share
+    (a one-GPU box is given 16 of the machine's CPUs)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env and env.isdigit() and int(env) > 0:
+        n = min(n, int(env))
+    return max(1, n)
 
 
 def cpu_baseline(scene, spec, rows):
@@ -191,7 +192,7 @@ def cpu_baseline(scene, spec, rows):
     from oracle import bridge
     import copy
 
-    threads = min(16, os.cpu_count() or 1)
+    threads = cpu_threads()
     s1 = copy.copy(spec)
     r0 = (spec.Height - rows) // 2
     with bridge.OracleScene(scene) as osc:
@@ -200,7 +201,7 @@ def cpu_baseline(scene, spec, rows):
         dt = time.perf_counter() - t0
     rays = c["rays_primary"] + c["rays_continuation"] + c["rays_shadow"]
     frac = rows / spec.Height / spec.AntiAliasingFactor
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{rows} middle rows x {spec.Width} px x 1 spp of the same frame ({rays} reference-equivalent rays, "
                       f"{dt:.1f} s); extrapolated full frame {dt / frac:.0f} s",
             "sec_per_frame_extrapolated": dt / frac}

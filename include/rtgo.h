@@ -123,6 +123,12 @@ typedef struct rt_partition {
     int64_t max_paths_per_batch; /* 0 = library default                               */
 } rt_partition;
 
+typedef struct rt_share {       /* what one rank of a partition renders (rt_partition_share)       */
+    int32_t sample_begin, sample_end; /* samples [begin, end) of each of its pixels                  */
+    int32_t tile_size, _pad;
+    int64_t n_tiles;             /* tiles of tile_size^2 pixels it owns (all of them unless RT_PART_TILES) */
+} rt_share;
+
 typedef struct rt_stats {
     uint64_t rays_primary;       /* closest-hit traversals at bounce 0                 */
     uint64_t rays_continuation;  /* closest-hit traversals at bounce > 0               */
@@ -206,6 +212,29 @@ int rt_resolve_device(const float* d_accum_rgb, int32_t width, int32_t height, i
 /* One-shot GenerateImage(imageSpec, scene): scene create + render + destroy. */
 int rt_generate_image(const rt_scene_desc* desc, const rt_image_spec* spec,
                       const rt_partition* part, uint8_t* rgba_out, rt_stats* stats);
+
+/* ---- one frame on several GPUs of one node, behind one blocking call ----------------------
+ * Replaces the goroutine fan-out inside GenerateImage (raytracer.go:73-87: WorkerCount workers fed from one
+ * job channel) with one host thread per device: the scene is replicated (rt_multi_create = rt_scene_create per
+ * device, all at once), share r of the frame — tiles k with k % n == r (RT_PART_TILES) or samples
+ * [r*spp/n, (r+1)*spp/n) (RT_PART_SAMPLES) — is rendered on devices[r] into that device's fp32 accumulation
+ * buffer, the buffers are summed onto devices[0] with one ncclReduce over xGMI (communicators from
+ * ncclCommInitAll, librccl opened on first need), devices[0] divides, quantises (raytracer.go:93-96,119) and
+ * copies the RGBA8 frame to rgba_out.  A sample's value does not depend on n (the Philox counter carries global
+ * pixel / sample indices): RT_PART_TILES frames are bit-identical for every n, RT_PART_SAMPLES frames up to the
+ * order of the float32 sums.  A device may be listed more than once (its shares are then summed on it without
+ * RCCL): a rehearsal of an n-share frame on fewer GPUs.  stats: counters summed, times = slowest share. */
+/* The share arithmetic on its own (no device needed): what rank `part->rank` of `part->world_size` renders. */
+int rt_partition_share(const rt_image_spec* spec, const rt_partition* part, rt_share* out);
+
+typedef struct rt_multi rt_multi;
+int rt_multi_create(const rt_scene_desc* desc, const int32_t* devices, int32_t n_devices, rt_multi** out);
+void rt_multi_destroy(rt_multi* multi);
+int rt_multi_render(rt_multi* multi, const rt_image_spec* spec, int32_t mode, uint64_t seed,
+                    uint8_t* rgba_out, rt_stats* stats);
+/* one shot: create + render + destroy */
+int rt_generate_image_multi(const rt_scene_desc* desc, const rt_image_spec* spec, const int32_t* devices,
+                            int32_t n_devices, int32_t mode, uint64_t seed, uint8_t* rgba_out, rt_stats* stats);
 
 /* Parity entry point: nearest hit of explicit rays, as bvh.trace(r, tMin)
  * (accelerationstructures.go:81-124).  rays: n * 8 floats {ox,oy,oz, dx,dy,dz, tMin, 0};

@@ -83,6 +83,11 @@ class RtStats(C.Structure):
         return self.rays_primary + self.rays_continuation + self.rays_shadow
 
 
+class RtShare(C.Structure):
+    _fields_ = [("sample_begin", C.c_int32), ("sample_end", C.c_int32), ("tile_size", C.c_int32), ("_pad", C.c_int32),
+                ("n_tiles", C.c_int64)]
+
+
 class RtSceneInfo(C.Structure):
     _fields_ = [("n_shapes", C.c_int64), ("n_inner_nodes", C.c_int64),
                 ("n_child_records", C.c_int64), ("tree_depth", C.c_int32),

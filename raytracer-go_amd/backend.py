@@ -16,7 +16,8 @@ LIB_PATH = os.path.join(_CSRC, "librtgo_hip.so")
 SYMBOLS = ("rt_last_error", "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info",
            "rt_render", "rt_render_accum_device", "rt_render_accum", "rt_resolve_device",
            "rt_generate_image", "rt_trace_rays", "rt_camera_rays", "rt_scatter_probe",
-           "rt_render_accum_device_static")
+           "rt_render_accum_device_static", "rt_multi_create", "rt_multi_destroy", "rt_multi_render", "rt_generate_image_multi",
+           "rt_partition_share")
 
 
 class RtgoError(RuntimeError):
@@ -59,6 +60,12 @@ def lib():
         L.rt_generate_image.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rt_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
         L.rt_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p]
+        L.rt_partition_share.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rt_multi_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+        L.rt_multi_destroy.argtypes = [C.c_void_p]
+        L.rt_multi_destroy.restype = None
+        L.rt_multi_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.rt_generate_image_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]
         L.rt_scatter_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         _lib = L
     return _lib
@@ -165,6 +172,49 @@ class DeviceScene:
         out = np.empty((pixels.shape[0], 6), dtype=np.float32)
         _check(lib().rt_camera_rays(self._h, C.addressof(s), seed, pixels.ctypes.data, pixels.shape[0], out.ctypes.data))
         return out
+
+
+def partition_share(spec, part):
+    """What one rank of a partition renders: (sample_begin, sample_end, n_tiles, tile_size).  Needs no device."""
+    s = _abi.image_spec(spec)
+    out = _abi.RtShare()
+    _check(lib().rt_partition_share(C.addressof(s), C.addressof(part), C.addressof(out)))
+    return out.sample_begin, out.sample_end, out.n_tiles, out.tile_size
+
+
+class MultiDeviceScene:
+    """A Scene replicated on several GPUs of one node (rt_multi): render() is one blocking call that splits the
+    frame over the devices and reduces the shares with RCCL onto the first one."""
+
+    def __init__(self, scene, devices):
+        self._h = C.c_void_p()
+        self._flat = _abi.FlatScene(scene)
+        self.devices = (C.c_int32 * len(devices))(*devices)
+        _check(lib().rt_multi_create(C.addressof(self._flat.desc), self.devices, len(devices), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rt_multi_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, spec, mode=_abi.RT_PART_TILES, seed=0x5EED):
+        s = _abi.image_spec(spec)
+        out = np.zeros((spec.Height, spec.Width, 4), dtype=np.uint8)
+        st = _abi.RtStats()
+        _check(lib().rt_multi_render(self._h, C.addressof(s), mode, seed, out.ctypes.data, C.addressof(st)))
+        return out, st
 
 
 def resolve_device(accum_ptr, width, height, spp, rgba_ptr, stream=None):

@@ -12,6 +12,8 @@
 //   resolve    raytracer.go:93-96,125                     1 lane / pixel -> RGBA8
 // Queues are compacted with a 64-lane ballot + popcount prefix and one atomic per 256-thread block.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: librccl is opened with dlopen when a multi-device frame needs it
 
 #include <chrono>
 #include <cmath>
@@ -502,6 +504,13 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const float* accum, int n_pi
     out[i] = px;
 }
 
+// accum[i] += other[i]: the shares of one frame summed on one device (only when a device is listed more than once,
+// i.e. a rehearsal on fewer GPUs than shares; distinct devices are reduced by RCCL)
+__global__ __launch_bounds__(kBlock) void k_add(float* accum, const float* other, size_t n) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) accum[i] += other[i];
+}
+
 __global__ __launch_bounds__(kBlock) void k_trace_probe(DScene S, Work Wk, const float* rays, uint32_t n, int any_hit,
                                                         int* prim_out, float* t_out) {
     __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
@@ -859,6 +868,24 @@ static int guarded(F&& f) noexcept {
     }
 }
 
+// f(rank) on one host thread per share; the first error (code + text) comes back on the calling thread
+template <class F>
+static int on_every_rank(int n, F&& f) {
+    std::vector<int> rc((size_t)n, RT_OK);
+    std::vector<std::string> msg((size_t)n);
+    {
+        ThreadGroup group;
+        for (int r = 1; r < n; ++r)
+            group.run([&, r] { rc[(size_t)r] = guarded([&] { return f(r); }); if (rc[(size_t)r] != RT_OK) msg[(size_t)r] = g_err; });
+        rc[0] = guarded([&] { return f(0); });
+        if (rc[0] != RT_OK) msg[0] = g_err;
+        group.join();
+    }
+    for (int r = 0; r < n; ++r)
+        if (rc[(size_t)r] != RT_OK) return fail(rc[(size_t)r], "share " + std::to_string(r) + ": " + msg[(size_t)r]);
+    return RT_OK;
+}
+
 extern "C" {
 
 const char* rt_last_error(void) { return g_err.c_str(); }
@@ -1103,6 +1130,20 @@ struct RenderPlan {
     bool by_tiles, empty;
 };
 
+// Which part of a frame a rank renders: tiles k with k % world == rank of the row-major tile grid, or the sample
+// range [rank * spp / world, (rank + 1) * spp / world) of every pixel.
+static void share_of(int W, int H, int spp, const rt_partition& part, int tile, rt_share* out) {
+    const long long tiles_x = (W + tile - 1) / tile, tiles_y = (H + tile - 1) / tile;
+    const long long n_tiles = tiles_x * tiles_y;
+    out->n_tiles = part.mode == RT_PART_TILES ? (n_tiles - part.rank + part.world_size - 1) / part.world_size : n_tiles;
+    out->sample_begin = 0; out->sample_end = spp;
+    if (part.mode == RT_PART_SAMPLES) {
+        out->sample_begin = (int)((long long)spp * part.rank / part.world_size);
+        out->sample_end = (int)((long long)spp * (part.rank + 1) / part.world_size);
+    }
+    out->tile_size = tile;
+}
+
 static int plan_render(const rt_scene* s, const rt_image_spec* spec, const rt_partition* part_in, int64_t paths_cap, RenderPlan* P) {
     int rc = validate_spec(spec);
     if (rc != RT_OK) return rc;
@@ -1118,16 +1159,11 @@ static int plan_render(const rt_scene* s, const rt_image_spec* spec, const rt_pa
     const int spp = spec->anti_aliasing_factor, reps = spec->soft_shadow_monte_carlo_repetitions;
     P->part = part; P->tile = tile;
     P->tiles_x = (W + tile - 1) / tile;
-    const int tiles_y = (H + tile - 1) / tile;
-    const long long n_tiles = (long long)P->tiles_x * tiles_y;
     P->by_tiles = part.mode == RT_PART_TILES;
-    const long long my_tiles = P->by_tiles ? (n_tiles - part.rank + part.world_size - 1) / part.world_size : n_tiles;
-    P->sA = 0; P->sB = spp;
-    if (part.mode == RT_PART_SAMPLES) {
-        P->sA = (int)((long long)spp * part.rank / part.world_size);
-        P->sB = (int)((long long)spp * (part.rank + 1) / part.world_size);
-    }
-    P->n_local_pixels = my_tiles * tile * tile;
+    rt_share sh{};
+    share_of(W, H, spp, part, tile, &sh);
+    P->sA = sh.sample_begin; P->sB = sh.sample_end;
+    P->n_local_pixels = sh.n_tiles * tile * tile;
     P->empty = !(P->sB > P->sA && D > 0 && P->n_local_pixels > 0);
     P->ns_max = 1; P->pix_per_batch = (long long)tile * tile; P->batch_paths = 0;
     // lanes per (hit, light) in the shadow kernel: smallest power of two >= min(reps, 64)
@@ -1421,6 +1457,133 @@ static int rt_scatter_probe_impl(rt_scene* s, const rt_image_spec* spec, uint64_
     return RT_OK;
 }
 
+// ---- one frame on several GPUs behind one call (what GenerateImage's goroutine fan-out becomes, raytracer.go:73-76) --
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static int load_rccl(Rccl* r) {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r->handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r->handle) break;
+    }
+    if (!r->handle) return fail(RT_ERR_DEVICE, std::string("librccl is not loadable: ") + dlerror());
+    r->CommInitAll = (decltype(r->CommInitAll))dlsym(r->handle, "ncclCommInitAll");
+    r->CommDestroy = (decltype(r->CommDestroy))dlsym(r->handle, "ncclCommDestroy");
+    r->Reduce = (decltype(r->Reduce))dlsym(r->handle, "ncclReduce");
+    r->GetErrorString = (decltype(r->GetErrorString))dlsym(r->handle, "ncclGetErrorString");
+    if (!r->CommInitAll || !r->CommDestroy || !r->Reduce || !r->GetErrorString) return fail(RT_ERR_DEVICE, "librccl lacks ncclCommInitAll / ncclReduce");
+    return RT_OK;
+}
+
+struct rt_multi {
+    std::vector<int> devices;
+    std::vector<rt_scene*> scenes;      // one replica of the scene per share
+    std::vector<hipStream_t> streams;   // one stream per share, on its device
+    std::vector<ncclComm_t> comms;      // when the devices are distinct and there are at least two
+    Rccl rccl;
+    bool distinct = true;
+};
+
+static void rt_multi_destroy_impl(rt_multi* m) {
+    if (!m) return;
+    for (size_t r = 0; r < m->comms.size(); ++r)
+        if (m->comms[r]) { (void)hipSetDevice(m->devices[r]); (void)m->rccl.CommDestroy(m->comms[r]); }
+    for (size_t r = 0; r < m->streams.size(); ++r)
+        if (m->streams[r]) { (void)hipSetDevice(m->devices[r]); (void)hipStreamDestroy(m->streams[r]); }
+    for (rt_scene* s : m->scenes) rt_scene_destroy(s);
+    if (m->rccl.handle) (void)dlclose(m->rccl.handle);
+    delete m;
+}
+
+static int rt_multi_create_impl(const rt_scene_desc* desc, const int32_t* devices, int32_t n, rt_multi** out) {
+    if (!desc || !devices || !out) return fail(RT_ERR_INVALID, "desc/devices/out is NULL");
+    *out = nullptr;
+    if (n < 1 || n > 64) return fail(RT_ERR_INVALID, "1 to 64 devices");
+    rt_multi* m = new rt_multi();
+    struct Guard { rt_multi* m; ~Guard() { if (m) rt_multi_destroy_impl(m); } } guard{m};
+    m->devices.assign(devices, devices + n);
+    m->scenes.assign((size_t)n, nullptr);
+    m->streams.assign((size_t)n, nullptr);
+    for (int a = 0; a < n; ++a)
+        for (int b = a + 1; b < n; ++b)
+            if (devices[a] == devices[b]) m->distinct = false;
+    // the replicas: tree build + upload per device, all at once (the builds are deterministic: every replica holds the same tree)
+    int rc = on_every_rank(n, [&](int r) {
+        int c = rt_scene_create(desc, m->devices[(size_t)r], &m->scenes[(size_t)r]);
+        if (c != RT_OK) return c;
+        HIP_TRY(hipSetDevice(m->devices[(size_t)r]));
+        HIP_TRY(hipStreamCreateWithFlags(&m->streams[(size_t)r], hipStreamNonBlocking));
+        return RT_OK;
+    });
+    if (rc != RT_OK) return rc;
+    if (n > 1 && m->distinct) {
+        rc = load_rccl(&m->rccl);
+        if (rc != RT_OK) return rc;
+        m->comms.assign((size_t)n, nullptr);
+        const ncclResult_t e = m->rccl.CommInitAll(m->comms.data(), n, m->devices.data());
+        if (e != ncclSuccess) return fail(RT_ERR_DEVICE, std::string("ncclCommInitAll: ") + m->rccl.GetErrorString(e));
+    }
+    guard.m = nullptr;
+    *out = m;
+    return RT_OK;
+}
+
+static int rt_multi_render_impl(rt_multi* m, const rt_image_spec* spec, int32_t mode, uint64_t seed, uint8_t* rgba_out, rt_stats* stats) {
+    if (!m || !rgba_out) return fail(RT_ERR_INVALID, "multi/rgba_out is NULL");
+    int rc = validate_spec(spec);
+    if (rc != RT_OK) return rc;
+    const int n = (int)m->scenes.size();
+    if (mode != RT_PART_TILES && mode != RT_PART_SAMPLES) return fail(RT_ERR_INVALID, "mode must be RT_PART_TILES or RT_PART_SAMPLES");
+    const size_t count = (size_t)spec->width * spec->height * 3;
+    std::vector<rt_stats> st((size_t)n);
+    rc = on_every_rank(n, [&](int r) {
+        rt_scene* s = m->scenes[(size_t)r];
+        hipStream_t stream = m->streams[(size_t)r];
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(s->accum.ensure(count * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(s->accum.p, 0, count * sizeof(float), stream));
+        rt_partition part{};
+        part.seed = seed; part.mode = mode; part.rank = r; part.world_size = n;
+        int c = rt_render_accum_device(s, spec, &part, (float*)s->accum.p, stream, &st[(size_t)r]);
+        if (c != RT_OK) return c;
+        if (!m->comms.empty()) {  // RCCL over xGMI: the shares summed onto the first device, in place there
+            const ncclResult_t e = m->rccl.Reduce(s->accum.p, s->accum.p, count, ncclFloat, ncclSum, 0, m->comms[(size_t)r], stream);
+            if (e != ncclSuccess) return fail(RT_ERR_DEVICE, std::string("ncclReduce: ") + m->rccl.GetErrorString(e));
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        return RT_OK;
+    });
+    if (rc != RT_OK) return rc;
+    rt_scene* root = m->scenes[0];
+    HIP_TRY(hipSetDevice(root->device));
+    if (m->comms.empty())  // shares that live on the root's own device (a device listed more than once): summed there
+        for (int r = 1; r < n; ++r) {
+            if (m->scenes[(size_t)r]->device != root->device) return fail(RT_ERR_DEVICE, "shares on several devices need RCCL");
+            hipLaunchKernelGGL(k_add, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, m->streams[0], (float*)root->accum.p,
+                               (const float*)m->scenes[(size_t)r]->accum.p, count);
+        }
+    HIP_TRY(root->rgba.ensure(count / 3 * 4));
+    rc = rt_resolve_device((const float*)root->accum.p, spec->width, spec->height, spec->anti_aliasing_factor, (uint8_t*)root->rgba.p, m->streams[0]);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(rgba_out, root->rgba.p, count / 3 * 4, hipMemcpyDeviceToHost, m->streams[0]));
+    HIP_TRY(hipStreamSynchronize(m->streams[0]));
+    if (stats) {
+        rt_stats t{};
+        for (const rt_stats& x : st) {
+            t.rays_primary += x.rays_primary; t.rays_continuation += x.rays_continuation; t.rays_shadow += x.rays_shadow;
+            t.rays_shadow_reference_equivalent += x.rays_shadow_reference_equivalent; t.phong_hits += x.phong_hits; t.paths += x.paths;
+            t.ms_build = std::max(t.ms_build, x.ms_build); t.ms_render = std::max(t.ms_render, x.ms_render);
+            t.ms_extend = std::max(t.ms_extend, x.ms_extend); t.ms_shadow = std::max(t.ms_shadow, x.ms_shadow); t.ms_shade = std::max(t.ms_shade, x.ms_shade);
+        }
+        *stats = t;
+    }
+    return RT_OK;
+}
+
 #ifdef RTGO_PROF
 int rt_debug_prof(unsigned long long* out8, int reset) {
     HIP_TRY(hipDeviceSynchronize());
@@ -1461,6 +1624,41 @@ int rt_trace_rays(rt_scene* s, const float* rays, int64_t n, int32_t any_hit, in
 }
 int rt_camera_rays(rt_scene* s, const rt_image_spec* spec, uint64_t seed, const int32_t* pixels, int64_t n, float* rays_out) {
     return guarded([&] { return rt_camera_rays_impl(s, spec, seed, pixels, n, rays_out); });
+}
+int rt_partition_share(const rt_image_spec* spec, const rt_partition* part, rt_share* out) {
+    return guarded([&] {
+        if (!part || !out) return fail(RT_ERR_INVALID, "part/out is NULL");
+        int rc = validate_spec(spec);
+        if (rc != RT_OK) return rc;
+        rt_partition p = *part;
+        if (p.mode < RT_PART_ALL || p.mode > RT_PART_SAMPLES) return fail(RT_ERR_INVALID, "unknown partition mode");
+        if (p.mode == RT_PART_ALL) { p.rank = 0; p.world_size = 1; }
+        if (p.world_size < 1 || p.rank < 0 || p.rank >= p.world_size) return fail(RT_ERR_INVALID, "bad rank/world_size");
+        const int tile = p.tile_size > 0 ? p.tile_size : 64;
+        if (tile % 8 != 0 || tile > 1024) return fail(RT_ERR_INVALID, "tile_size must be a multiple of 8, at most 1024");
+        share_of(spec->width, spec->height, spec->anti_aliasing_factor, p, tile, out);
+        return RT_OK;
+    });
+}
+int rt_multi_create(const rt_scene_desc* desc, const int32_t* devices, int32_t n_devices, rt_multi** out) {
+    return guarded([&] { return rt_multi_create_impl(desc, devices, n_devices, out); });
+}
+void rt_multi_destroy(rt_multi* m) { (void)guarded([&] { rt_multi_destroy_impl(m); return RT_OK; }); }
+int rt_multi_render(rt_multi* m, const rt_image_spec* spec, int32_t mode, uint64_t seed, uint8_t* rgba_out, rt_stats* stats) {
+    return guarded([&] { return rt_multi_render_impl(m, spec, mode, seed, rgba_out, stats); });
+}
+int rt_generate_image_multi(const rt_scene_desc* desc, const rt_image_spec* spec, const int32_t* devices, int32_t n_devices, int32_t mode,
+                            uint64_t seed, uint8_t* rgba_out, rt_stats* stats) {
+    return guarded([&] {
+        int rc = validate_spec(spec);
+        if (rc != RT_OK) return rc;
+        rt_multi* m = nullptr;
+        rc = rt_multi_create_impl(desc, devices, n_devices, &m);
+        if (rc != RT_OK) return rc;
+        rc = rt_multi_render_impl(m, spec, mode, seed, rgba_out, stats);
+        rt_multi_destroy_impl(m);
+        return rc;
+    });
 }
 int rt_scatter_probe(rt_scene* s, const rt_image_spec* spec, uint64_t seed, const float* rays, const uint32_t* keys, int64_t n, float* out) {
     return guarded([&] { return rt_scatter_probe_impl(s, spec, seed, rays, keys, n, out); });

@@ -148,9 +148,13 @@ def _room(half=6.0, height=8.0, depth_front=-10.0, depth_back=6.0, mats=None):
     ]
 
 
+ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")  # holds samples_textures/ like the reference's repository root
+
+
 def _tile_texture(asset_dir):
-    """The one image asset the reference ships (samples_textures/Tiles075_1K_Color.jpg); falls
-    back to a checkerboard when the fixture directory is not there."""
+    """The one image asset the reference ships (samples_textures/Tiles075_1K_Color.jpg, kept under the package's
+    assets/); falls back to a checkerboard when the directory is not there."""
+    asset_dir = asset_dir or ASSET_DIR
     if asset_dir:
         path = os.path.join(asset_dir, "samples_textures", "Tiles075_1K_Color.jpg")
         if os.path.exists(path):

@@ -1,7 +1,7 @@
 """Measures the ALGORITHMIC traversal work per ray with the CPU oracle's float64 best-first
 traversal (the reference's own, accelerationstructures.go:81-124): mean inner nodes expanded
 (N_inner) and leaf shapes tested (N_leaf) per ray class, on a reduced-resolution pass over each
-config.  B_ray = 224*N_inner + 40*N_leaf + 56 bytes.  Output: tests/golden/bray.json.
+config.  B_ray = 224*N_inner + 40*N_leaf + 56 bytes.  Output: profiles/bray.json.
 """
 import importlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,5 +26,5 @@ for name, (spec, scene), (w, h, spp) in (
         row[cls] = {"n_inner": ni, "n_leaf": nl, "bytes_per_ray": 224 * ni + 40 * nl + 56}
     out[name] = row
     print(name, {k: row[k] for k in ("primary", "continuation", "shadow")}, flush=True)
-with open(os.path.join(GOLD, "bray.json"), "w") as f:
+with open(os.path.join(ROOT, "profiles", "bray.json"), "w") as f:
     json.dump(out, f, indent=1)

@@ -125,3 +125,52 @@ def test_cpp_example_renders_the_same_bytes_as_python(rt, gold_dir, asset_dir, t
     spec.AntiAliasingFactor = 4
     want = rt.GenerateImage(spec, scene).Pix
     assert (got == want).all()
+
+
+def _write_shim_scene(rt, spec, scene, path):
+    """The flattened scene as the C structs of include/rtgo.h (tests/cpp/shim_sequence.c documents the layout)."""
+    abi = rt._abi
+    flat = abi.FlatScene(scene)
+    d = flat.desc
+    texs = C.cast(d.textures, C.POINTER(abi.RtTexture))
+    with open(path, "wb") as f:
+        f.write(np.array([d.n_shapes, d.n_materials, d.n_textures, d.n_lights], dtype=np.int64).tobytes())
+        f.write(bytes(abi.image_spec(spec)))
+        for v in (d.camera_look_from, d.camera_look_at, d.camera_up):
+            f.write(bytes(v))
+        f.write(np.array([d.camera_aperture, d.camera_fov_deg], dtype=np.float64).tobytes())
+        f.write(flat.shapes.tobytes())
+        f.write(C.string_at(d.materials, C.sizeof(abi.RtMaterial) * d.n_materials))
+        pixels = []
+        for i in range(d.n_textures):
+            t = abi.RtTexture.from_buffer_copy(C.string_at(C.addressof(texs[i]), C.sizeof(abi.RtTexture)))
+            if t.kind == abi.RT_TEX_IMAGE:
+                pixels.append(C.string_at(t.rgba, t.width * t.height * 4))
+            t.rgba = None
+            f.write(bytes(t))
+        f.write(C.string_at(d.lights, C.sizeof(abi.RtLight) * d.n_lights))
+        for p in pixels:
+            f.write(p)
+
+
+@pytest.mark.gpu
+def test_shim_call_sequence_in_c_renders_the_same_bytes_as_python(rt, gold_dir, tmp_path):
+    """INTEGRATION.md's cgo shim cannot be compiled here (no Go): examples/shim_sequence performs its exact C-side call
+    sequence — C-allocated tables, rt_scene_create(desc, 0, &s), rt_render(s, &spec, NULL, pix, &stats),
+    rt_scene_destroy — on the flattened ExampleRegression and must produce the bytes of the Python twin."""
+    exe = os.path.join(ROOT, "examples", "shim_sequence")
+    assert os.path.exists(exe), "examples/shim_sequence is built by __graft_entry__.build()"
+    spec, scene = rt.ExampleRegression(160, 95, gold_dir)
+    spec.AntiAliasingFactor = 4
+    _write_shim_scene(rt, spec, scene, tmp_path / "scene.bin")
+    p = subprocess.run([exe, str(tmp_path / "scene.bin"), str(tmp_path / "frame.rgba")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert "Finished building BoundingVolumeHierarchy" in p.stdout and "Finished ray tracing in" in p.stdout
+    got = np.fromfile(tmp_path / "frame.rgba", dtype=np.uint8).reshape(95, 160, 4)
+    want = rt.GenerateImage(spec, scene).Pix
+    assert (got == want).all()
+    # the reference's panic on an unknown algorithm id comes back through rt_last_error (accelerationstructures.go:73)
+    spec.BvhTraversalAlgorithm = 7
+    _write_shim_scene(rt, spec, scene, tmp_path / "bad.bin")
+    p = subprocess.run([exe, str(tmp_path / "bad.bin"), str(tmp_path / "bad.rgba")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 1 and "No trace algorithm found for 7" in p.stderr

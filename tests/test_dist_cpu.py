@@ -1,6 +1,7 @@
-"""N > 1 path on CPU: world_size-2 gloo run of the frame driver (raytracer-go_amd/dist.py).  The
-device renderer is replaced by the CPU oracle restricted to the rank's sample range — the checker
-standing in for the GPU — so this covers the partition + reduce(sum) + resolve logic."""
+"""N > 1 path on CPU: a world_size-2 gloo run of the frame loop that bench.py --gpus N drives
+(raytracer-go_amd/dist.py: backend choice, process-group set-up, FrameLoop.step = zero + share + reduce(sum) +
+resolve on rank 0, FrameLoop.aggregate = max time / summed counters).  Only the share renderer is replaced: the
+CPU oracle restricted to the rank's sample range stands in for the device, the checker in the GPU's place."""
 import importlib
 import os
 import sys
@@ -19,21 +20,32 @@ def _worker(rank, world, port, out_path):
     rtdist = importlib.import_module("raytracer-go_amd.dist")
     from oracle import bridge
 
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = rtdist.pick_backend(world, 0)  # no device here: gloo
+    assert backend == "gloo"
+    rtdist.init_process_group(rank, world, backend)
     spec, scene = rt.ExampleRegression(96, 57, os.path.join(ROOT, "tests", "golden"))
     spec.AntiAliasingFactor = 6
     accum = torch.zeros((spec.Height, spec.Width, 3), dtype=torch.float64)
+    frames = []
     with bridge.OracleScene(scene) as osc:
         def share(part):
+            assert (part.rank, part.world_size, part.mode) == (rank, world, rt._abi.RT_PART_SAMPLES)
             s0, s1 = rtdist.sample_range(spec.AntiAliasingFactor, part.rank, part.world_size)
-            a, _, _ = osc.render(spec, seed=part.seed, mode=bridge.F64_DIJKSTRA, threads=2, samples=(s0, s1), rgba=False)
+            a, _, c = osc.render(spec, seed=part.seed, mode=bridge.F64_DIJKSTRA, threads=2, samples=(s0, s1), rgba=False)
             accum.add_(torch.from_numpy(a))
-        rtdist.render_frame(share, accum, spec, rt._abi.RT_PART_SAMPLES, rank, world,
-                            reduce_fn=lambda a: dist.reduce(a, dst=0, op=dist.ReduceOp.SUM))
+            return {"rays": c["rays_primary"] + c["rays_continuation"] + c["rays_shadow"], "paths": (s1 - s0) * spec.Width * spec.Height}
+
+        loop = rtdist.FrameLoop(spec, rt._abi.RT_PART_SAMPLES, rank, world, accum, share, resolve=lambda a: frames.append(a.clone().numpy()))
+        counters = [loop.step() for _ in range(2)]  # two frames: the buffer is zeroed per step
+        loop.fence()
+        elapsed, sums = loop.aggregate(1.0 + rank, [counters[-1]["rays"], counters[-1]["paths"]])
+    assert elapsed == float(world)  # the slowest rank's time
+    assert sums[1] == spec.Width * spec.Height * spec.AntiAliasingFactor
+    assert (len(frames) == 2) == (rank == 0)
     if rank == 0:
-        np.save(out_path, accum.numpy())
+        assert np.array_equal(frames[0], frames[1])
+        np.save(out_path, frames[1])
     dist.barrier()
     dist.destroy_process_group()
 

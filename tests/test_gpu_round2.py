@@ -149,3 +149,33 @@ def test_binary_stl_path_on_the_device(backend, scenes, rt, tmp_path, monkeypatc
     assert (out[0][0] >= 2).mean() > 0.1  # the mesh is on screen
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][2], out[1][2]) and out[0][3] == out[1][3]
+
+
+def test_multi_device_frame_behind_one_call(backend, rt, c1, hip_buffers):
+    """rt_multi_*: one blocking call renders a frame on a list of devices (one host thread and one scene replica per
+    share, RCCL reduce onto the first device, resolve there).  One share must equal rt_render byte for byte; a tile
+    split reassembles bit-exactly, a sample split up to the order of the float32 sums (at most one step of the
+    RGBA8 quantiser).  With a single GPU the shares sit on device 0 and are summed there; with two or more visible
+    the same frames go over RCCL."""
+    import ctypes
+
+    abi = rt._abi
+    spec, scene = rt.ExampleRegression(320, 190, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    spec.AntiAliasingFactor = 8
+    with backend.DeviceScene(scene) as dev:
+        want, st1 = dev.render(spec)
+    n_dev = ctypes.c_int()
+    assert hip_buffers.hip.hipGetDeviceCount(ctypes.byref(n_dev)) == 0 and n_dev.value >= 1
+    lists = [[0], [0, 0], [0, 0, 0]] + ([[0, 1]] if n_dev.value >= 2 else []) + ([list(range(min(8, n_dev.value)))] if n_dev.value >= 3 else [])
+    for devices in lists:
+        with backend.MultiDeviceScene(scene, devices) as multi:
+            for mode in (abi.RT_PART_TILES, abi.RT_PART_SAMPLES):
+                got, st = multi.render(spec, mode=mode)
+                assert st.paths == st1.paths and st.rays_shadow == st1.rays_shadow and st.rays_continuation == st1.rays_continuation
+                if mode == abi.RT_PART_TILES or len(devices) == 1:
+                    assert np.array_equal(got, want), (devices, mode)
+                else:
+                    d = np.abs(got.astype(int) - want.astype(int))
+                    assert d.max() <= 1 and (d > 0).mean() < 1e-3, (devices, d.max(), (d > 0).mean())
+    with pytest.raises(backend.RtgoError):
+        backend.MultiDeviceScene(scene, [0, 99])

@@ -25,7 +25,7 @@ def test_abi_struct_layout(rt):
     a = rt._abi
     assert ctypes.sizeof(a.RtVec3) == 24 and ctypes.sizeof(a.RtShape) == 88 and ctypes.sizeof(a.RtMaterial) == 64
     assert ctypes.sizeof(a.RtTexture) == 88 and ctypes.sizeof(a.RtLight) == 112 and ctypes.sizeof(a.RtImageSpec) == 32
-    assert ctypes.sizeof(a.RtPartition) == 32 and ctypes.sizeof(a.RtSceneInfo) == 40
+    assert ctypes.sizeof(a.RtPartition) == 32 and ctypes.sizeof(a.RtSceneInfo) == 40 and ctypes.sizeof(a.RtShare) == 24
 
 
 def test_no_gpu_fails_loudly(backend):
@@ -127,6 +127,28 @@ def test_sample_split_covers_all_samples():
         for world in (1, 2, 3, 8):
             r = [d.sample_range(spp, k, world) for k in range(world)]
             assert r[0][0] == 0 and r[-1][1] == spp and all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+
+
+def test_partition_shares_cover_the_frame(backend, rt):
+    """rt_partition_share (the share arithmetic of rt_render_accum_device and rt_multi_render, no device needed):
+    over the ranks of a world the sample ranges tile [0, spp) in order and the tile counts add up to the tile grid."""
+    import importlib
+    abi = rt._abi
+    d = importlib.import_module("raytracer-go_amd.dist")
+    for (W, H, tile) in ((640, 380, 64), (1920, 1080, 64), (100, 37, 8), (3840, 2160, 128)):
+        n_tiles = -(-W // tile) * -(-H // tile)
+        for spp in (1, 7, 64, 1024):
+            spec = rt.ImageSpec(W, H, spp, 16, 16, 1, 0)
+            for world in (1, 2, 3, 8):
+                sh = [backend.partition_share(spec, abi.partition(mode=abi.RT_PART_SAMPLES, rank=r, world_size=world, tile_size=tile)) for r in range(world)]
+                assert [x[:2] for x in sh] == [d.sample_range(spp, r, world) for r in range(world)]
+                assert sh[0][0] == 0 and sh[-1][1] == spp and all(sh[i][1] == sh[i + 1][0] for i in range(world - 1))
+                assert all(x[2] == n_tiles and x[3] == tile for x in sh)
+                th = [backend.partition_share(spec, abi.partition(mode=abi.RT_PART_TILES, rank=r, world_size=world, tile_size=tile)) for r in range(world)]
+                assert sum(x[2] for x in th) == n_tiles and all(x[:2] == (0, spp) for x in th)
+                assert [x[2] for x in th] == [len([k for k in range(n_tiles) if d.tile_owner(k, world) == r]) for r in range(world)]
+    with pytest.raises(backend.RtgoError):
+        backend.partition_share(rt.ImageSpec(64, 64, 1, 1, 1, 1, 0), abi.partition(mode=abi.RT_PART_TILES, rank=2, world_size=2))
 
 
 def test_tree_builders_under_sanitizers(tmp_path):
