@@ -194,7 +194,7 @@ int rt_render_accum_device(rt_scene* scene, const rt_image_spec* spec, const rt_
  * that every GPU the library runs on holds until the process ends, instead of memory the scene allocates on
  * demand.  The call makes no hipMalloc / hipFree / hipHostMalloc / hipEventCreate; per-stage times
  * (ms_extend, ms_shadow) are not measured.  Limits (RT_ERR_LIMIT beyond): tile_size^2 <= 262144 paths per batch,
- * at most 4 positional lights, RayTracingMaxDepth <= 64, a scene whose tree needs at most 51 traversal-stack
+ * at most 4 positional lights, RayTracingMaxDepth <= 64, a scene whose tree needs at most 54 traversal-stack
  * entries (rt_scene_info.stack_bound + 1).  All calls on one GPU share that GPU's array: two of them that
  * overlap in time (two host threads, two streams) race; successive calls need nothing from each other. */
 int rt_render_accum_device_static(rt_scene* scene, const rt_image_spec* spec, const rt_partition* part,

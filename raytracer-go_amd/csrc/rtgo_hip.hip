@@ -378,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_compact(Work Wk, const uint32_t
 // a power of two <= 64; each lane runs repetitions r, r+group, ...  The visible repetitions of a
 // (hit, light) are counted with a ballot popcount: integer, so the result has no summation order.
 #ifndef RTGO_SHADOW_WAVES
-#define RTGO_SHADOW_WAVES 5
+#define RTGO_SHADOW_WAVES 6  // k_shadow ms per frame at config 3 (quantised walk): 5 waves (LDS stack 20) 416, 6 (15) 395, 7 (11) 392, 8 (8) 404
 #endif
 __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, Batch B, Work Wk, const uint32_t* n_hits_ptr, int bounce,
                                                    int group, int group_shift, const uint32_t* pair_counter) {
@@ -712,8 +712,8 @@ struct rt_scene {
 constexpr int64_t kStaticPaths = (int64_t)1 << 18;  // (pixel, sample) paths of one batch
 constexpr int kStaticLights = 4;                    // positional lights
 constexpr int kStaticDepth = 64;                    // RayTracingMaxDepth
-constexpr int kStaticSpill = 32;                    // traversal-stack entries per lane beyond the LDS part
-constexpr int kStaticGrid = 1024;                   // blocks of a grid-stride launch (the spill region is per thread of it)
+constexpr int kStaticSpill = 40;                    // traversal-stack entries per lane beyond the LDS part
+constexpr int kStaticGrid = 768;                    // blocks of a grid-stride launch (the spill region is per thread of it)
 constexpr size_t kScratchBytes = (size_t)72 << 20;
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 

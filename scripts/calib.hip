@@ -38,6 +38,25 @@ __global__ __launch_bounds__(256, WAVES) void k_valu(float* out, float seed, uns
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// the same with packed fp32 (v_pk_fma_f32: two fma per lane and instruction): does it issue at the scalar rate?
+typedef float float2v __attribute__((ext_vector_type(2)));
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_valu_pk(float* out, float seed, unsigned long long* cycles) {
+    float2v a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = float2v{seed + (float)(threadIdx.x + i), seed - (float)i};
+    const float2v m = {1.0000001f, 0.9999999f}, c = {1e-9f, 2e-9f};
+    for (int it = 0; it < kIters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = __builtin_elementwise_fma(a[i], m, c);
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += a[i].x + a[i].y;
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = 0;
+}
+
 template <int WAVES, int RECS>
 __global__ __launch_bounds__(256, WAVES) void k_gather(const float4* __restrict__ table, uint32_t mask, int share, float* out,
                                                       unsigned long long* cycles) {
@@ -111,6 +130,12 @@ int main() {
         c = mean_cycles(cus * 8);
         printf(", \"valu_8waves_per_simd\": {\"ms\": %.4f, \"cycles_per_inst_per_simd_in_kernel\": %.3f, \"cycles_per_inst_per_simd_by_event\": %.3f}", ms,
                c / (insts * 8), ms * 1e-3 * clk_hz / (insts * 8));
+    }
+    {   // 8 x kIters packed fma per thread = the flops of the scalar loop in half the instructions
+        float ms;
+        if (timed([&] { hipLaunchKernelGGL(k_valu_pk<5>, dim3(cus * 5), dim3(256), 0, 0, out, 1.0f, cyc); }, &ms)) return 1;
+        printf(", \"valu_pk_fma_5waves_per_simd\": {\"ms\": %.4f, \"cycles_per_pk_inst_per_simd_by_event\": %.3f}", ms,
+               ms * 1e-3 * clk_hz / (8.0 * kIters * 5));
     }
     // ---- gather: per thread kIters/8 rounds x RECS records x 2 dwordx4 loads; 5 waves per SIMD (k_shadow's occupancy)
     {

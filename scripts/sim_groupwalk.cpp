@@ -192,7 +192,7 @@ extern "C" int sim_groupwalk(const orc_scene* s, const rt_image_spec* spec, uint
                 if (rec && nr < rec_cap) {
                     float* q = rec + nr * 8;
                     q[0] = (float)rays.size(); q[1] = (float)nocc; q[2] = (float)pair_inner; q[3] = (float)pair_leaf;
-                    q[4] = (float)visits; q[5] = (float)touched; q[6] = (float)hit.shape; q[7] = (float)li;
+                    q[4] = (float)visits; q[5] = (float)touched; q[6] = (float)bmax; q[7] = (float)li;
                     ++nr;
                 }
             }
@@ -317,6 +317,78 @@ extern "C" int sim_hints(const orc_scene* s, const rt_image_spec* spec, uint64_t
                             for (int u = 0; u < up && a != root; ++u) a = parent[a];
                             hint = a;
                         }
+                    }
+                }
+            }
+        }
+    return 0;
+}
+
+// ---- third experiment: what do shadow rays spend their shape tests on? --------------------------------------
+// out: [0] rays, [1] shape tests, [2] of them on the first `n_big` shapes of the scene (config 3: the 10 room triangles),
+//      [3] leaves entered, [4] leaves entered that hold one of those shapes, [5] block visits
+extern "C" int sim_big_shapes(const orc_scene* s, const rt_image_spec* spec, uint64_t seed, int n_big, double* out) {
+    const Scene& sc = s->sc;
+    const int W = spec->width, H = spec->height, reps = spec->soft_shadow_monte_carlo_repetitions;
+    const CameraF64 c64 = new_camera(sc, W, H);
+    const Camera<float> cf = narrow_camera<float>(c64);
+    const Tables<float>& T = sc.t32;
+    Node* root = effective(sc.wide_root);
+    const int leaf_size = sc.leaf_size;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    std::vector<int> group;
+    for (int row = 0; row < H; ++row)
+        for (int i = 0; i < W; ++i) {
+            const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(row * W + i), 0u};
+            const Ray<float> r = camera_ray(cf, W, H, i, H - 1 - row, key);
+            Hit<float> hit;
+            if (!trace_stack_f32(sc, r, 0.0f, FLT_MAX, false, hit, nullptr)) continue;
+            const Material<float>& m = T.materials[T.shapes[hit.shape].material];
+            if (m.kind != RT_MAT_PHONGBLINN) continue;
+            int lpos = -1;
+            for (size_t li = 0; li < T.lights.size(); ++li) {
+                const Light<float>& L = T.lights[li];
+                if (L.kind == RT_LIGHT_AMBIENT) continue;
+                ++lpos;
+                const V3<float> ldir = unit(sub(L.pos, hit.p));
+                if (saturate(dot(hit.normal, ldir)) == 0.0f && std::pow(saturate(dot(hit.normal, unit(add(ldir, r.d)))), m.param) == 0.0f) continue;
+                for (int k = 0; k < reps; ++k) {
+                    const V3<float> jit = scale(0.25f, random_in_unit_sphere<float>(key, 0, P_SHADOW, (uint32_t)(lpos * reps + k)));
+                    const V3<float> shifted = add(L.pos, jit);
+                    if (L.kind == RT_LIGHT_SPOT && !(dot(L.look_dir, unit(sub(hit.p, shifted))) >= L.cos_angle)) continue;
+                    const V3<float> ld = sub(shifted, hit.p);
+                    const float d = norm(ld);
+                    const Ray<float> ray{hit.p, scale(1.0f / d, ld)};
+                    const StackRay sr = make_stack_ray(ray);
+                    out[0] += 1;
+                    std::vector<Node*> stack;
+                    Node* cur = root;
+                    bool done = false;
+                    while (!done) {
+                        out[5] += 1;
+                        Node* pending[8]; int np = 0;
+                        for (int q = 0; q < 8 && !done; ++q) {
+                            Node* e = cur->slot[q ^ sr.sign];
+                            if (!e || !slab_f32(sr, e->fmin, e->fmax, 0.01f, d)) continue;
+                            if (e->count > leaf_size) { pending[np++] = e; continue; }
+                            group.clear();
+                            subtree_shapes(e, &group);
+                            out[3] += 1;
+                            bool has_big = false;
+                            for (int shape : group) has_big = has_big || shape < n_big;
+                            if (has_big) out[4] += 1;
+                            for (int shape : group) {
+                                out[1] += 1;
+                                if (shape < n_big) out[2] += 1;
+                                const Hit<float> sh = triangle_occludes_f32(T.shapes[(size_t)shape], shape, ray, 0.01f, d);
+                                if (sh.t > 0.0f && sh.t <= d) { done = true; break; }
+                            }
+                        }
+                        if (done) break;
+                        for (int q = np - 1; q >= 1; --q) stack.push_back(pending[q]);
+                        if (np > 0) { cur = pending[0]; continue; }
+                        if (stack.empty()) break;
+                        cur = stack.back(); stack.pop_back();
                     }
                 }
             }
