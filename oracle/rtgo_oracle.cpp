@@ -170,6 +170,7 @@ struct Node {
     // F32_STACK helpers (filled after the build)
     float fmin[3], fmax[3];
     int count = 0;  // shapes in the subtree
+    bool as_leaf = false;  // the device flattener makes ONE leaf of this subtree (mark_leaves)
     Node* slot[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // device block rooted here
 };
 
@@ -353,7 +354,28 @@ inline double node_area(const Node* n) {
     const double dx = n->pmax.x - n->pmin.x, dy = n->pmax.y - n->pmin.y, dz = n->pmax.z - n->pmin.z;
     return 2.0 * ((dx * dy + dy * dz) + dz * dx);
 }
-void build_block(Node* x, int leaf_size, bool collapse) {
+// The device flattener's leaf rule (csrc/octree.cpp is_leaf), restated: at most leaf_size shapes, and the box either
+// small (less than 1/64 of the area of the scene's box) or tight (at most 1.5 x the area of the largest single-shape
+// box in it); a subtree of few but disparate large shapes stays a block of smaller leaves.
+double max_shape_area(const Node* n) {
+    if (n->leaf) return n->shape >= 0 ? node_area(n) : 0.0;
+    double m = 0;
+    for (const Node* c : n->children) if (c) m = std::max(m, max_shape_area(c));
+    return m;
+}
+void mark_leaves(Node* n, int leaf_size, double root_area) {
+    n->as_leaf = false;
+    if (n->count <= leaf_size) {
+        if (n->count <= 1 || n->leaf) n->as_leaf = true;
+        else {
+            const double a = node_area(n);
+            n->as_leaf = a * 64.0 < root_area || a <= 1.5 * max_shape_area(n);
+        }
+    }
+    if (!n->leaf)
+        for (Node* c : n->children) if (c) mark_leaves(c, leaf_size, root_area);
+}
+void build_block(Node* x, bool collapse) {
     int n = 0;
     for (int o = 0; o < 8; ++o) {
         x->slot[o] = x->children[o] ? effective(x->children[o]) : nullptr;
@@ -365,7 +387,7 @@ void build_block(Node* x, int leaf_size, bool collapse) {
         double pick_area = 0;
         for (int s = 0; s < 8; ++s) {
             Node* e = x->slot[s];
-            if (!e || e->count <= leaf_size) continue;
+            if (!e || e->as_leaf) continue;
             int k = 0;
             for (Node* c : e->children) if (c) ++k;
             if (n - 1 + k > 8) continue;
@@ -400,13 +422,14 @@ void build_block(Node* x, int leaf_size, bool collapse) {
 }
 void build_blocks(Node* root, int leaf_size) {
     const bool collapse = std::getenv("RTGO_NO_COLLAPSE") == nullptr;
+    mark_leaves(root, leaf_size, node_area(effective(root)));
     std::vector<Node*> todo{effective(root)};
     while (!todo.empty()) {
         Node* x = todo.back();
         todo.pop_back();
-        if (x->leaf || x->count <= leaf_size) continue;
-        build_block(x, leaf_size, collapse);
-        for (Node* e : x->slot) if (e && e->count > leaf_size) todo.push_back(e);
+        if (x->leaf || x->as_leaf) continue;
+        build_block(x, collapse);
+        for (Node* e : x->slot) if (e && !e->as_leaf) todo.push_back(e);
     }
 }
 
@@ -818,9 +841,8 @@ bool trace_stack_f32(const Scene& sc, const Ray<float>& r, float tmin, float tma
     bool found = false;
     std::vector<Node*> stack;
     Node* root = effective(sc.tree_kind == 1 && sc.wide_root ? sc.wide_root : sc.root);
-    const int leaf_size = sc.leaf_size < 1 ? 1 : sc.leaf_size;
     Node fake;  // a root that is itself one leaf gets a synthetic one-child parent, as in the device flattener
-    if (root->count <= leaf_size) {
+    if (root->as_leaf || root->count == 0) {
         if (root->count == 0) { out = hr; return false; }
         fake.leaf = false; fake.has_children = true; fake.slot[0] = root;
         root = &fake;
@@ -838,7 +860,7 @@ bool trace_stack_f32(const Scene& sc, const Ray<float>& r, float tmin, float tma
             Node* e = cur->slot[k ^ sr.sign];  // chain-skipped already: same box as the un-collapsed child after the refit
             if (!e) continue;
             if (!slab_f32(sr, e->fmin, e->fmax, t0, entry_best)) continue;
-            if (e->count <= leaf_size) leaves[nl++] = e; else pending[np++] = e;
+            if (e->as_leaf) leaves[nl++] = e; else pending[np++] = e;
         }
         // pass 2: hit leaf children in ray order; a leaf's shapes in their stored (depth-first) order
         for (int q = 0; q < nl; ++q) {

@@ -506,7 +506,34 @@ static double box_area(const HostNode& n) {
     const double dx = n.hi[0] - n.lo[0], dy = n.hi[1] - n.lo[1], dz = n.hi[2] - n.lo[2];
     return 2.0 * ((dx * dy + dy * dz) + dz * dx);
 }
-static void block_slots(const std::vector<HostNode>& nodes, int32_t x, int leaf_size, int32_t slot[8]) {
+// Which subtrees become ONE leaf: at most leaf_size shapes, and either a small box or a tight one.  A leaf's shapes
+// are all tested by every ray that meets the leaf's box; for a handful of small neighbouring triangles that is cheaper
+// than another block visit, but NOT for shapes that only a builder's bookkeeping put together: the 6 largest triangles
+// of a box room ended up in one leaf whose box was the whole room, and every shadow ray of config 3 paid 6 of its 15
+// shape tests there (scripts/sim_groupwalk.cpp sim_big_shapes).  So a subtree whose box has at least 1/64 of the area
+// of the scene's box becomes a leaf only if that box is hardly larger (x 1.5 in area) than the largest box of a single
+// shape in it — two triangles of one wall — and is otherwise kept as a block of smaller leaves, whose flat boxes
+// nearly every ray misses.  Mirrored by the oracle (rtgo_oracle.cpp mark_leaves).
+struct LeafRule {
+    int leaf_size;
+    double root_area;
+};
+static double max_shape_area(const std::vector<HostNode>& nodes, int32_t n) {
+    if (nodes[n].child_base < 0) return nodes[n].shape >= 0 ? box_area(nodes[n]) : 0.0;
+    double m = 0;
+    for (int o = 0; o < 8; ++o)
+        if (!nodes[nodes[n].child_base + o].empty) m = std::max(m, max_shape_area(nodes, nodes[n].child_base + o));
+    return m;
+}
+static bool is_leaf(const std::vector<HostNode>& nodes, int32_t e, const LeafRule& rule) {
+    if (nodes[e].n_shapes > rule.leaf_size) return false;
+    if (nodes[e].n_shapes <= 1 || nodes[e].child_base < 0) return true;
+    const double a = box_area(nodes[e]);
+    if (a * 64.0 < rule.root_area) return true;
+    return a <= 1.5 * max_shape_area(nodes, e);
+}
+
+static void block_slots(const std::vector<HostNode>& nodes, int32_t x, const LeafRule& rule, int32_t slot[8]) {
     int n = 0;
     for (int o = 0; o < 8; ++o) {
         const int32_t c = nodes[x].child_base + o;
@@ -521,7 +548,7 @@ static void block_slots(const std::vector<HostNode>& nodes, int32_t x, int leaf_
         double pick_area = 0;
         for (int s = 0; s < 8; ++s) {
             const int32_t e = slot[s];
-            if (e < 0 || nodes[e].n_shapes <= leaf_size) continue;
+            if (e < 0 || is_leaf(nodes, e, rule)) continue;
             const int k = n_children(nodes, e);
             if (n - 1 + k > 8) continue;
             const double a = box_area(nodes[e]);
@@ -637,7 +664,8 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
     std::vector<Block> blocks;
     std::unordered_map<int64_t, int64_t> block_of_first;
     const int32_t root = skip_chain(nodes, 0);
-    if (nodes[root].n_shapes <= leaf_size) {
+    const LeafRule rule{leaf_size, box_area(nodes[root])};
+    if (is_leaf(nodes, root, rule)) {
         // everything fits one leaf: synthetic root block with that leaf in octant 0
         ChildRecord r;
         set_box(root, &r);
@@ -657,7 +685,7 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
         const HostNode& nd = nodes[p.node];
         const int64_t first = (int64_t)out->records.size();
         int32_t slot[8];
-        block_slots(nodes, p.node, leaf_size, slot);
+        block_slots(nodes, p.node, rule, slot);
         uint32_t present = 0, leaf_mask = 0, child_base = 0;
         for (int o = 0; o < 8; ++o) {
             const int32_t e = slot[o];
@@ -665,7 +693,7 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
             present |= 1u << o;
             ChildRecord r;
             set_box(e, &r);
-            if (nodes[e].n_shapes <= leaf_size) {
+            if (is_leaf(nodes, e, rule)) {
                 make_leaf(e, &r);
                 leaf_mask |= 1u << o;
             } else {

@@ -150,7 +150,7 @@ extern "C" int sim_groupwalk(const orc_scene* s, const rt_image_spec* spec, uint
                     std::vector<Node*> stack;
                     Node* cur = root;
                     std::vector<int> group;
-                    if (root->count <= leaf_size) { cur = nullptr; }
+                    if (root->as_leaf) { cur = nullptr; }
                     while (cur && undecided > 0) {
                         visits += 1;
                         Node* pending[8]; int np = 0;
@@ -159,7 +159,7 @@ extern "C" int sim_groupwalk(const orc_scene* s, const rt_image_spec* spec, uint
                             if (!e) continue;
                             const bool hitb = tight ? beam_box_tight(B, e->fmin, e->fmax) : beam_box(B, e->fmin, e->fmax);
                             if (!hitb) continue;
-                            if (e->count <= leaf_size) {
+                            if (e->as_leaf) {
                                 touched += 1;
                                 group.clear();
                                 subtree_shapes(e, &group);
@@ -229,7 +229,7 @@ WalkResult walk_from(const Scene& sc, Node* start, const Ray<float>& r, float tm
             Node* e = cur->slot[k ^ sr.sign];
             if (!e) continue;
             if (!slab_f32(sr, e->fmin, e->fmax, tmin, tmax)) continue;
-            if (e->count <= leaf_size) leaves[nl++] = e; else pending[np++] = e;
+            if (e->as_leaf) leaves[nl++] = e; else pending[np++] = e;
         }
         for (int q = 0; q < nl; ++q) {
             group.clear();
@@ -268,7 +268,7 @@ extern "C" int sim_hints(const orc_scene* s, const rt_image_spec* spec, uint64_t
         std::vector<Node*> st{root};
         while (!st.empty()) {
             Node* n = st.back(); st.pop_back();
-            for (Node* e : n->slot) if (e) { parent[e] = n; if (e->count > leaf_size) st.push_back(e); }
+            for (Node* e : n->slot) if (e) { parent[e] = n; if (!e->as_leaf) st.push_back(e); }
         }
     }
     for (int i = 0; i < 8; ++i) out[i] = 0;
@@ -370,7 +370,7 @@ extern "C" int sim_big_shapes(const orc_scene* s, const rt_image_spec* spec, uin
                         for (int q = 0; q < 8 && !done; ++q) {
                             Node* e = cur->slot[q ^ sr.sign];
                             if (!e || !slab_f32(sr, e->fmin, e->fmax, 0.01f, d)) continue;
-                            if (e->count > leaf_size) { pending[np++] = e; continue; }
+                            if (!e->as_leaf) { pending[np++] = e; continue; }
                             group.clear();
                             subtree_shapes(e, &group);
                             out[3] += 1;
