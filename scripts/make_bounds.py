@@ -1,0 +1,66 @@
+"""profiles/r02/bounds.json from one run of scripts/profile_r02.sh: per-frame counter totals of k_shadow (PMC passes over
+bench.py --steps 1 --warmup 0, which renders the cold frame and one timed frame) + the unit rates calibrated on the
+same box (scripts/calib.hip).  bench.py prices the kernel's live time against them.
+    python scripts/make_bounds.py gpurun_out/prof_<tag> profiles/r02 <tag>"""
+import ast
+import json
+import os
+import re
+import shutil
+import sys
+
+src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+os.makedirs(dst, exist_ok=True)
+
+
+def kernel_counters(path, kernel="k_shadow"):
+    for line in open(path):
+        m = re.match(rf"^{kernel} calls (\d+) (\{{.*\}})\s*$", line)
+        if m:
+            return int(m.group(1)), {k: float(v) for k, v in ast.literal_eval(m.group(2)).items()}
+    raise SystemExit(f"no {kernel} line in {path}")
+
+
+calls, u = kernel_counters(os.path.join(src, "pmc_units.txt"))
+_, f = kernel_counters(os.path.join(src, "pmc_fetch.txt"))
+_, l2 = kernel_counters(os.path.join(src, "pmc_l2.txt"))
+launches = 16                      # k_shadow launches per 1080p 64-spp frame (16 batches of 2^23 paths)
+frames = calls / launches          # bench.py --steps 1 --warmup 0 renders the cold frame + one step
+calib = json.load(open(os.path.join(src, "calib.json")))
+clock_hz = calib["clock_mhz"] * 1e6
+cus = calib["cus"]
+l1_hit = 1024.0 / calib["gather_l1_share1"]["lane_bytes_per_cycle_per_cu"]   # cycles per wave-load with 64 distinct L1-resident records
+l2_srv = 1024.0 / calib["gather_share1"]["lane_bytes_per_cycle_per_cu"]     # ... with 64 distinct L2-served records
+out = {
+    "workload": {"width": 1920, "height": 1080, "spp": 64, "config": "config3"},
+    "kernel": "k_shadow", "launches_per_frame": launches, "frames_profiled": frames, "tag": tag,
+    "per_frame": {
+        "valu_insts": u["SQ_INSTS_VALU"] / frames,
+        "salu_insts": u["SQ_INSTS_SALU"] / frames,
+        "vmem_read_insts": u["SQ_INSTS_VMEM_RD"] / frames,
+        "lds_insts": u["SQ_INSTS_LDS"] / frames,
+        "tcp_accesses": u["TCP_TOTAL_CACHE_ACCESSES_sum"] / frames,
+        "tcp_l2_read_req": u["TCP_TCC_READ_REQ_sum"] / frames,
+        "ta_busy_frac": u["TA_BUSY_avr"] / (u["GRBM_GUI_ACTIVE"] / 8.0),   # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        "ta_busy_max_frac": u["TA_BUSY_max"] / (u["GRBM_GUI_ACTIVE"] / 8.0),
+        "wave_cycles_waiting_frac": u["SQ_WAIT_ANY"] / u["SQ_WAVE_CYCLES"],
+        "wave_cycles_issue_stalled_frac": u["SQ_WAIT_INST_ANY"] / u["SQ_WAVE_CYCLES"],
+        "gpu_cycles_per_xcd": u["GRBM_GUI_ACTIVE"] / 8.0 / frames,
+        "hbm_fetch_bytes": f["FETCH_SIZE"] * 1024.0 / frames,     # rocprofv3 reports KiB
+        "hbm_write_bytes": l2["WRITE_SIZE"] * 1024.0 / frames,
+        "l2_hit_rate": l2["TCC_HIT_sum"] / (l2["TCC_HIT_sum"] + l2["TCC_MISS_sum"]),
+    },
+    "calib": {
+        "clock_hz": clock_hz, "cus": cus, "simds": 4 * cus,
+        "valu_cycles_per_wave_inst_per_simd": calib["valu_5waves_per_simd"]["cycles_per_inst_per_simd_by_event"],
+        "tcp_l1_hit_accesses_per_clk_per_cu": 64.0 / l1_hit,
+        "tcp_l2_served_accesses_per_clk_per_cu": 64.0 / l2_srv,
+        "note": "scripts/calib.hip on the same box: register-only v_fma_f32 stream at 5 waves per SIMD; 16-byte-per-lane gathers of "
+                "64 distinct 32-byte records per wave instruction from a 16 KiB (L1-resident) and an 8 MiB (L2-served) table; "
+                "rocprofv3 counts 64 TCP_TOTAL_CACHE_ACCESSES for such an instruction (profiles/r02/calib_pmc.txt)",
+    },
+}
+json.dump(out, open(os.path.join(dst, "bounds.json"), "w"), indent=1)
+for name in ("kernel_stats.csv", "pmc_units.txt", "pmc_fetch.txt", "pmc_l2.txt", "calib.json"):
+    shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
+print(json.dumps(out["per_frame"], indent=1))
