@@ -412,7 +412,7 @@ RT_DEV QRay make_qray(f3 o, f3 d) {
 RT_DEV float qbyte(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); }  // v_cvt_f32_ubyteN
 // Slab tests of the 8 slots of block `blk` in SLOT order.  hit: bit per slot whose box the ray meets inside
 // [tmin, tmax]; h1 = {child base | leaf mask << 24, first leaf shape, meta bytes of slots 0..3, 4..7}.
-RT_DEV uint32_t visit_qblock(const DScene& S, uint32_t blk, const QRay& r, float tmin, float tmax, uint4* h1_out) {
+RT_DEV uint32_t visit_qblock(const DScene& S, uint32_t blk, const QRay& r, float tmin, float tmax, uint4* h1_out, uint32_t* present_out) {
     RT_PROF_POINT(0);  // block visits
     const uint4* q = S.qblocks + 5 * (size_t)blk;
     const uint4 h0 = q[0], h1 = q[1], qa = q[2], qb = q[3], qc = q[4];
@@ -441,6 +441,7 @@ RT_DEV uint32_t visit_qblock(const DScene& S, uint32_t blk, const QRay& r, float
         hit |= tn <= tf ? (1u << k) : 0u;
     }
     *h1_out = h1;
+    *present_out = h0.w >> 24;
     return hit & (h0.w >> 24);
 }
 // slot-order mask -> ray-order mask: position k holds slot k ^ sign (three conditional swaps)
@@ -474,8 +475,10 @@ RT_DEV void queue_qleaves(uint32_t* pend, uint32_t stride, const uint4& h1, uint
     }
     *npend = n;
 }
-// Hit inner children pushed far-to-near in RAY order, the nearest then popped (as next_block()).
-RT_DEV bool next_qblock(const TraceStack& st, const uint4& h1, uint32_t inner_hits, uint32_t sign, uint32_t* cur, int* sp_io) {
+// Hit inner children in RAY order: the nearest is entered, the others pushed far to near.  A child's block is the
+// block's first child block + its rank among the inner children (slot order).
+#ifdef RTGO_PUSH_BRANCHFREE
+RT_DEV bool next_qblock(const TraceStack& st, const uint4& h1, uint32_t, uint32_t inner_hits, uint32_t sign, uint32_t* cur, int* sp_io) {
     int sp = *sp_io;
     if (inner_hits) {
         const uint32_t m = ray_order8(inner_hits, sign);
@@ -501,6 +504,34 @@ RT_DEV bool next_qblock(const TraceStack& st, const uint4& h1, uint32_t inner_hi
     *sp_io = sp;
     return true;
 }
+#else
+// One loop iteration per hit inner child beyond the nearest (0.9 hit inner children per visit on average): the
+// branch-free form above stores and counts all 8 slots on every visit (66 VALU + 9 LDS operations).
+RT_DEV bool next_qblock(const TraceStack& st, const uint4& h1, uint32_t present, uint32_t inner_hits, uint32_t sign, uint32_t* cur, int* sp_io) {
+    int sp = *sp_io;
+    if (inner_hits) {
+        uint32_t m = ray_order8(inner_hits, sign);
+        const uint32_t base = h1.x & 0xffffffu;
+        const uint32_t inner = present & ~(h1.x >> 24);  // the slots that hold inner children
+        const int kn = __ffs((int)m) - 1;             // nearest: lowest ray-order position
+        m &= m - 1u;
+        while (m) {
+            const int k = 31 - __clz((int)m);          // farthest first
+            m ^= 1u << k;
+            const uint32_t slot = (uint32_t)k ^ sign;
+            st.put(sp++, base + (uint32_t)__popc(inner & ((1u << slot) - 1u)));
+        }
+        const uint32_t slot = (uint32_t)kn ^ sign;
+        *cur = base + (uint32_t)__popc(inner & ((1u << slot) - 1u));
+        *sp_io = sp;
+        return true;
+    }
+    if (sp == 0) return false;
+    *cur = st.get(--sp);
+    *sp_io = sp;
+    return true;
+}
+#endif
 
 // Inclusive scans over the 64 lanes of a wavefront through the DPP path (shifts within rows of 16 lanes,
 // then the last lane of a row broadcast to the rows after it); every lane of the wavefront must be active.
@@ -605,7 +636,7 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
 
     for (;;) {
         uint4 h1 = make_uint4(0u, 0u, 0u, 0u);
-        uint32_t leaf_mask = 0, inner_mask = 0;
+        uint32_t leaf_mask = 0, inner_mask = 0, present = 0;
 #ifdef RTGO_PROF
         {   // per iteration of the walk: lanes that only hold leaves, lanes with nothing to do
             const unsigned long long hold = __ballot(!walking && npend > 0u), idle = __ballot(!walking && npend == 0u);
@@ -617,7 +648,7 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
         }
 #endif
         if (walking) {  // a box that ends before tmin holds no accepted hit
-            const uint32_t hit = visit_qblock(S, cur, r, tmin, tmax, &h1);
+            const uint32_t hit = visit_qblock(S, cur, r, tmin, tmax, &h1, &present);
             leaf_mask = hit & (h1.x >> 24);
             inner_mask = hit & ~(h1.x >> 24);
         }
@@ -626,7 +657,7 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
             if (occ) leaf_mask = 0u;  // this lane's ray is decided: nothing more to queue
         }
         queue_qleaves(pend, st.lds_stride, h1, leaf_mask, &npend);
-        if (walking) walking = next_qblock(st, h1, inner_mask, r.sign, &cur, &sp);
+        if (walking) walking = next_qblock(st, h1, present, inner_mask, r.sign, &cur, &sp);
         const int n_walking = __popcll(__ballot(walking));
         const int n_holding = __popcll(__ballot(npend > 0u));
         if (n_holding > 0 && n_holding >= (n_walking < kFlushLanes ? n_walking : kFlushLanes)) flush();
