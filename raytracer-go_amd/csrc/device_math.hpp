@@ -431,14 +431,20 @@ RT_DEV uint32_t visit_qblock(const DScene& S, uint32_t blk, const QRay& r, float
     near_[2][0] = nz ? qc.z : qb.x; near_[2][1] = nz ? qc.w : qb.y; far_[2][0] = nz ? qb.x : qc.z; far_[2][1] = nz ? qb.y : qc.w;
     uint32_t hit = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 7; k >= 0; --k) {  // slot 7 first: every slot shifts the mask left and adds its bit
         const int w = k >> 2, b = k & 3;
         // a NaN (0 * inf for a direction component of 0) drops out of fmaxf / fminf: that axis then culls nothing
         const float tn = fmaxf(fmaxf(fmaf(qbyte(near_[0][w], b), sx, bx), fmaf(qbyte(near_[1][w], b), sy, by)),
                                fmaxf(fmaf(qbyte(near_[2][w], b), sz, bz), tmin));
         const float tf = fminf(fminf(fmaf(qbyte(far_[0][w], b), sx, bx), fmaf(qbyte(far_[1][w], b), sy, by)),
                                fminf(fmaf(qbyte(far_[2][w], b), sz, bz), tmax));
-        hit |= tn <= tf ? (1u << k) : 0u;
+#ifdef RTGO_HITMASK_SELECT
+        hit = (hit << 1) | (tn <= tf ? 1u : 0u);
+#else
+        // hit = 2 * hit + (tn <= tf): the compare's lane mask goes in as the carry of an add (2 instructions per slot
+        // instead of compare + select + or)
+        asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hit) : "v"(tn), "v"(tf) : "vcc");
+#endif
     }
     *h1_out = h1;
     *present_out = h0.w >> 24;
