@@ -46,6 +46,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -248,7 +249,10 @@ struct Builder {
     }
     // accelerationstructures.go:226-255 (iterative on the descent, recursive on the split)
     void add_shape(Node* cur, int shape) {
-        for (;;) {
+        for (int level = 0;; ++level) {
+            // the reference never ends on two centroids its jitter cannot separate (the device's octree builder refuses
+            // such a scene the same way, csrc/octree.cpp build_octree)
+            if (level > 1300) throw std::invalid_argument("centroids that the insertion octree cannot separate");
             if (cur->leaf) {
                 if (cur->shape < 0) { cur->shape = shape; return; }
                 cur->leaf = false;
@@ -1279,7 +1283,13 @@ orc_scene* orc_scene_create(const rt_scene_desc* d) {
     }
     narrow_tables(sc.t64, sc.t32);
     Builder b{sc};
-    b.build();
+    try {
+        b.build();
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        delete o;
+        return nullptr;
+    }
     fill_f32_boxes(sc.root);
     build_blocks(sc.root, sc.leaf_size);
     sc.wide_root = build_wide_tree(sc, sc.leaf_size);

@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
+#include <string>
 #include <deque>
 #include <unordered_map>
 #include <atomic>
@@ -115,6 +117,7 @@ int32_t skip_chain(const std::vector<HostNode>& nodes, int32_t n) {
 
 }  // namespace
 
+constexpr int kMaxOctreeLevels = 1300;
 std::vector<HostNode> build_octree(const rt_shape* shapes, int64_t n) {
     std::vector<HostNode> nodes;
     nodes.reserve((size_t)(n * 4 + 16));
@@ -136,7 +139,14 @@ std::vector<HostNode> build_octree(const rt_shape* shapes, int64_t n) {
     Jitter rng;
     for (int64_t i = 0; i < n; ++i) {
         int32_t cur = 0;
-        for (;;) {
+        for (int level = 0;; ++level) {
+            // Two shapes whose centroids the 1e-10 jitter cannot tell apart (equal centroids at |c| >~ 1e6, where the
+            // jitter is below one ulp) land in the same octant at every level: the cell's half-width reaches 0 and the
+            // reference recurses until its stack overflows (accelerationstructures.go:226-255).  A cell can be halved
+            // about 1200 times between 1e30 and the smallest double; beyond that the scene is refused.
+            if (level > kMaxOctreeLevels)
+                throw std::invalid_argument("shapes " + std::to_string(nodes[cur].shape >= 0 ? nodes[cur].shape : i) + " and " + std::to_string(i) +
+                                            " have centroids that the insertion octree cannot separate (RTGO_TREE=octree; the default tree has no such limit)");
             if (nodes[cur].child_base < 0) {
                 if (nodes[cur].shape < 0) { nodes[cur].shape = (int32_t)i; break; }
                 const int32_t evicted = nodes[cur].shape;

@@ -861,6 +861,8 @@ static int guarded(F&& f) noexcept {
         return f();
     } catch (const std::bad_alloc&) {
         return fail(RT_ERR_LIMIT, "out of host memory");
+    } catch (const std::invalid_argument& e) {
+        return fail(RT_ERR_INVALID, e.what());
     } catch (const std::exception& e) {
         return fail(RT_ERR_DEVICE, std::string("host runtime error: ") + e.what());
     } catch (...) {

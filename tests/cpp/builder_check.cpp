@@ -185,6 +185,17 @@ int main() {
         unsetenv("RTGO_BUILD_THREADS");
         check_scene("two clusters, threaded", v, 6);
     }
+    {   // equal centroids where the reference's 1e-10 jitter is below one ulp: its insertion octree never ends
+        // (accelerationstructures.go:226-279); build_octree refuses the scene, build_sah (no jitter, ranges halved
+        // when nothing separates them) builds it
+        std::vector<rt_shape> v{sphere(1e8, 1e8, 1e8, 0.5), sphere(1e8, 1e8, 1e8, 0.25), sphere(0, 0, 0, 1)};
+        bool refused = false;
+        try { (void)build_octree(v.data(), (int64_t)v.size()); } catch (const std::invalid_argument&) { refused = true; }
+        CHECK(refused, "build_octree did not refuse inseparable centroids");
+        FlatTree t;
+        const char* err = nullptr;
+        CHECK(flatten_octree(build_sah(v.data(), (int64_t)v.size(), 6), 6, &t, &err) && t.order.size() == 3, "build_sah failed on inseparable centroids");
+    }
     {   // the builders' threads: an exception in a worker comes back on the starting thread, after every worker has ended
         std::atomic<int> done{0};
         bool thrown = false;
