@@ -951,6 +951,30 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     if (rc != RT_OK) return rc;
 
     const auto t0 = std::chrono::steady_clock::now();
+    // RTGO_TIMING=1: the phases of scene creation on stderr (host tree build, flattening, tables, uploads)
+    const bool timing = std::getenv("RTGO_TIMING") != nullptr;
+    auto lap = [&, last = t0](const char* what) mutable {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[rtgo] scene create: %-10s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    };
+    // The HIP runtime sets up its copy path on the first hipMemcpy of the process (about 150 ms on an MI355X box,
+    // RTGO_TIMING=1; a first hipMalloc alone does not trigger it): a thread pays that with a small copy and memset
+    // while this one builds the tree, and is joined before the first upload (one-shot frame 0.83 s -> 0.71 s).
+    struct Warm {
+        std::thread t;
+        void join() { if (t.joinable()) t.join(); }
+        ~Warm() { join(); }
+    } warm;
+    warm.t = std::thread([device] {
+        void* p = nullptr;
+        std::vector<char> host((size_t)4 << 20, 1);
+        if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, host.size()) != hipSuccess) return;
+        (void)hipMemcpy(p, host.data(), host.size(), hipMemcpyHostToDevice);
+        (void)hipMemset(p, 0, host.size());
+        (void)hipFree(p);
+    });
     FlatTree flat;
     {
         const char* err = nullptr;
@@ -963,8 +987,11 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
         const std::vector<HostNode> nodes = octree
                                                 ? build_octree(desc->shapes, desc->n_shapes)
                                                 : build_sah(desc->shapes, desc->n_shapes, leaf_size);
+        lap("tree");
         if (!flatten_octree(nodes, leaf_size, &flat, &err)) return fail(RT_ERR_LIMIT, err);
+        lap("flatten");
     }
+    lap("free nodes");
     // shapes -> 3 float4 each, narrowed to fp32 (round to nearest), stored in leaf order
     // tprims: the same records for the intersection tests, with the triangle's edges e1 = B - A, e2 = C - A (fp32
     // differences of the fp32 vertices, exactly what the tests would compute) in place of B and C
@@ -1001,6 +1028,9 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
         d.param = (float)m.param;
     }
 
+    lap("tables");
+    warm.join();
+    lap("hip warm");
     rt_scene* s = new rt_scene();
     struct Guard {  // an exception (std::bad_alloc in a table, std::system_error from a thread) must not leak the device buffers
         rt_scene* s;
@@ -1036,6 +1066,7 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
             tex_bytes += (int64_t)n;
         }
     }
+    lap("textures");
     std::vector<DLight> lights((size_t)desc->n_lights + 1);
     int n_pos = 0;
     for (int64_t i = 0; i < desc->n_lights; ++i) {
@@ -1076,6 +1107,7 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     HIP_TRY_S(hipMalloc(&s->d_lights, lights.size() * sizeof(DLight)));
     HIP_TRY_S(hipMemcpy(s->d_lights, lights.data(), lights.size() * sizeof(DLight), hipMemcpyHostToDevice));
 
+    lap("uploads");
     // traversal stack spill: worst case 7 pending siblings per level, beyond the LDS part
     const int spill = flat.stack_bound + 1 > kLdsStackDepth ? flat.stack_bound + 1 - kLdsStackDepth : 0;  // +1: the nearest child is pushed, then popped
     s->spill = spill;  // the region itself is sized by ensure_overflow() for the grids a call really launches
@@ -1095,6 +1127,7 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     s->info.tree_depth = flat.depth; s->info.stack_bound = flat.stack_bound;
     s->info.device_bytes = (int64_t)(rec_bytes + flat.qblocks.size() * 4 + prims.size() * 4 + tprims.size() * 4 + mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
                                      lights.size() * sizeof(DLight)) + tex_bytes;  // + the spill region, see ensure_overflow()
+    lap("events");
     s->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     guard.s = nullptr;
     *out = s;
