@@ -77,7 +77,7 @@ def main():
     rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     keys = ("rays", "rays_primary", "rays_continuation", "rays_shadow", "rays_shadow_reference_equivalent",
-            "ms_extend", "ms_shadow", "ms_shade")
+            "ms_extend", "ms_shadow", "ms_shade", "ms_render")
 
     lib_build = {"s": 0.0}
 
@@ -104,7 +104,12 @@ def main():
             totals[k] += v
     loop.fence()
     elapsed, sums = loop.aggregate(time.perf_counter() - t0, [totals[k] for k in keys] + [one_shot])
-    rays, n_prim, n_cont, n_shadow, n_shadow_ref, ms_extend, ms_shadow, ms_shade, one_shot_sum = sums
+    rays, n_prim, n_cont, n_shadow, n_shadow_ref, ms_extend, ms_shadow, ms_shade, _ms_render, one_shot_sum = sums
+    # after the timed region: this rank's share once more on ONE lane (RTGO_LANES=1), where no other kernel runs
+    # beside k_shadow, so its launch durations are those of the kernel alone (roofline["alone"])
+    os.environ["RTGO_LANES"] = "1"
+    alone = share(loop.part)
+    del os.environ["RTGO_LANES"]
 
     if rank == 0:
         with open(os.path.join(ROOT, "profiles", "bray.json")) as f:
@@ -134,6 +139,12 @@ def main():
                                     "shade_phong_other": ms_shade / args.steps / world},
             "roofline": roofline(shadow_s, n_shadow / args.steps / world, world, W, H, spec.AntiAliasingFactor, bray),
         }
+        # the same kernel with the GPU to itself (rank 0's share, one lane): what the kernel sustains when no
+        # HBM-bound kernel of the other lane takes time slices from it
+        r1 = roofline(alone["ms_shadow"] / 1e3, alone["rays_shadow"], world, W, H, spec.AntiAliasingFactor, bray)
+        out["roofline"]["alone"] = {"kernel_s_per_frame": r1["kernel_s_per_frame"], "achieved": r1["achieved"], "frac": r1["frac"],
+                                    "frame_ms_one_lane": alone["ms_render"]}
+        out["roofline"]["lanes"] = int(os.environ.get("RTGO_LANES", "2"))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, spec, args.cpu_rows)
         print(json.dumps(out), flush=True)
@@ -152,7 +163,11 @@ def roofline(shadow_s, shadow_rays, world, W, H, spp, bray):
     rocprofv3 PMC passes over this same command (profiles/r02/bounds.json: instruction and access counts are
     properties of the workload, identical from run to run for a seed); what each unit sustains per clock comes
     from the micro-benchmarks of scripts/calib.hip run on the same box (same file).  frac = busy time of the
-    busiest unit / the kernel's measured time (HIP events around every k_shadow launch of the timed region)."""
+    busiest unit / the kernel's measured time (HIP events around every k_shadow launch of the timed region).
+    A render call runs its batches on two streams (rtgo_hip.hip Lane): in the timed region a k_shadow launch shares
+    the GPU with the other lane's HBM-bound kernels (and at times with its k_shadow), so its duration includes the
+    time slices they got and `frac` is lower than the kernel's own; roofline["alone"] is the same measurement over
+    one more frame rendered on a single lane."""
     out = {"bound": None, "kernel": "k_shadow", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
            "kernel_s_per_frame": shadow_s}
     # SURVEY 8d's figure, kept for the record: the REFERENCE's traversal bytes (its octree, 224 B per node) per second

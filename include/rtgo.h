@@ -139,7 +139,10 @@ typedef struct rt_stats {
     uint64_t paths;              /* (pixel, sample) pairs rendered by this call        */
     double ms_build;             /* host tree build + flatten + upload (scene create)  */
     double ms_render;            /* device time of the render call (hipEvent)          */
-    double ms_extend, ms_shadow, ms_shade; /* per-stage device time, if timed          */
+    double ms_extend, ms_shadow, ms_shade; /* per-stage stream time, if timed: the launch durations of k_extend and of
+                                    k_shadow, and the rest of each stream's span.  A render call runs its batches on
+                                    two streams that overlap (RTGO_LANES=1: one), the stage times are summed over
+                                    them, so the three can add up to more than ms_render.                        */
 } rt_stats;
 
 typedef struct rt_scene_info {

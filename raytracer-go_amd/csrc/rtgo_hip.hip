@@ -685,6 +685,26 @@ struct Arena {
 
 constexpr int kSnapshots = 3;  // pinned copies of the counter block: two alternate per bounce, one for the end of a call
 
+// What one stream of batches needs for itself.  A render call deals its batches out over kLanes lanes, each with a
+// host thread, a stream and a workspace of its own: k_shadow is bound by VALU issue and everything else in a batch
+// by HBM, so one lane's ray generation, nearest-hit walk, shading and accumulation run under the other's shadow
+// rays (config 3: 393 -> 373 ms per frame; with the k_shadow launches of the two lanes made to take turns through
+// events, so that two of them never share the GPU: 381 ms).  A launch's duration now includes the time slices the
+// other lane's kernels got, so the per-kernel times of a two-lane frame add up to more than the frame
+// (RTGO_LANES=1 measures a kernel alone).  A pixel's batches always go to the same lane, in the order of the
+// single-lane loop, so the frame is bit-identical for any number of lanes.
+struct Lane {
+    Arena arena;     // grown on demand
+    uint32_t* h_counters = nullptr;  // pinned, kSnapshots * h_counter_words
+    size_t h_counter_words = 0;
+    hipEvent_t ev_snap[2] = {}, ev_frame[2] = {};
+    bool ev_ok = false;
+    std::vector<hipEvent_t> ev_pool;  // per-stage timing of a call that asks for stats: 4 per (batch, bounce), reused
+    hipStream_t stream = nullptr;     // lanes beyond the first: their own stream (lane 0 runs on the caller's)
+    hipEvent_t ev_join = nullptr;
+};
+constexpr int kLanes = 2;
+
 struct rt_scene {
     int device = 0;
     DScene d{};
@@ -694,13 +714,9 @@ struct rt_scene {
     double ms_build = 0;
     // camera inputs (NewCamera needs the aspect ratio, so the camera is finished per render)
     rt_vec3 from, at, up; double aperture = 0, fov = 0;
-    Arena arena;     // grown on demand
+    Lane lanes[kLanes];
     int spill = 0;   // traversal-stack entries beyond the LDS part (from the tree's exact worst case)
-    uint32_t* h_counters = nullptr;  // pinned, kSnapshots * h_counter_words
-    size_t h_counter_words = 0;
-    hipEvent_t ev_snap[2] = {}, ev_frame[2] = {};
-    bool ev_ok = false;
-    std::vector<hipEvent_t> ev_pool;  // per-stage timing of a call that asks for stats: 4 per (batch, bounce), reused
+    hipEvent_t ev_fork = nullptr, ev_wall[2] = {};
     DevBuf accum, rgba, probe_in, probe_out, probe_out2;
 };
 
@@ -757,8 +773,8 @@ inline unsigned long long grid_blocks(unsigned long long lanes, int cap) {
     return blocks > (unsigned long long)cap ? (unsigned long long)cap : blocks;
 }
 
-int ensure_work(rt_scene* s, int64_t paths, int depth, int lpos, unsigned long long lanes) {
-    Arena& a = s->arena;
+int ensure_work(rt_scene* s, Lane& ln, int64_t paths, int depth, int lpos, unsigned long long lanes) {
+    Arena& a = ln.arena;
     const unsigned long long stride = grid_blocks(lanes, a.grid_cap) * kBlock;
     const unsigned long long entries = s->spill > 0 ? (unsigned long long)(s->spill + 1) * stride : 0ull;
     if (a.base && paths <= a.paths && depth <= a.depth && lpos <= a.lpos && entries <= a.overflow_entries) {
@@ -778,17 +794,18 @@ int ensure_work(rt_scene* s, int64_t paths, int depth, int lpos, unsigned long l
     a.paths = np; a.depth = nd; a.lpos = nl; a.overflow_entries = ne;
     a.wk.overflow_stride = s->spill > 0 ? (uint32_t)(ne / (unsigned long long)(s->spill + 1)) : 0u;
     const size_t words = (size_t)(3 * nd + 8);
-    if (words > s->h_counter_words) {
-        if (s->h_counters) { (void)hipHostFree(s->h_counters); s->h_counters = nullptr; s->h_counter_words = 0; }
-        HIP_TRY(hipHostMalloc((void**)&s->h_counters, kSnapshots * words * sizeof(uint32_t)));
-        s->h_counter_words = words;
+    if (words > ln.h_counter_words) {
+        if (ln.h_counters) { (void)hipHostFree(ln.h_counters); ln.h_counters = nullptr; ln.h_counter_words = 0; }
+        HIP_TRY(hipHostMalloc((void**)&ln.h_counters, kSnapshots * words * sizeof(uint32_t)));
+        ln.h_counter_words = words;
     }
     return RT_OK;
 }
 
 // Makes the spill region large enough for a probe launch over `lanes` rays (the render workspace is kept).
 int ensure_overflow(rt_scene* s, unsigned long long lanes) {
-    return ensure_work(s, std::max<int64_t>(1, s->arena.paths), std::max(1, s->arena.depth), std::max(1, s->arena.lpos), lanes);
+    const Arena& a = s->lanes[0].arena;
+    return ensure_work(s, s->lanes[0], std::max<int64_t>(1, a.paths), std::max(1, a.depth), std::max(1, a.lpos), lanes);
 }
 
 // NewCamera, camera.go:18-35, with the arguments GenerateImage passes (raytracer.go:59-68)
@@ -1116,11 +1133,18 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     s->d.materials = (const DMaterial*)s->d_mats; s->d.textures = (const DTexture*)s->d_texs;
     s->d.lights = (const DLight*)s->d_lights;
     s->d.n_lights = (int)desc->n_lights; s->d.n_pos_lights = n_pos; s->d.root_ref = flat.root_ref;
-    s->h_counter_words = (size_t)(3 * kStaticDepth + 8);
-    HIP_TRY_S(hipHostMalloc((void**)&s->h_counters, kSnapshots * s->h_counter_words * sizeof(uint32_t)));
-    for (auto& e : s->ev_snap) HIP_TRY_S(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto& e : s->ev_frame) HIP_TRY_S(hipEventCreate(&e));
-    s->ev_ok = true;
+    for (int l = 0; l < kLanes; ++l) {
+        Lane& ln = s->lanes[l];
+        ln.ev_ok = true;  // from here on rt_scene_destroy() releases whatever of the lane exists
+        ln.h_counter_words = (size_t)(3 * kStaticDepth + 8);
+        HIP_TRY_S(hipHostMalloc((void**)&ln.h_counters, kSnapshots * ln.h_counter_words * sizeof(uint32_t)));
+        for (auto& e : ln.ev_snap) HIP_TRY_S(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : ln.ev_frame) HIP_TRY_S(hipEventCreate(&e));
+        HIP_TRY_S(hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
+        if (l > 0) HIP_TRY_S(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+    }
+    HIP_TRY_S(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    for (auto& e : s->ev_wall) HIP_TRY_S(hipEventCreate(&e));
 
     s->info.n_shapes = desc->n_shapes; s->info.n_inner_nodes = flat.n_inner;
     s->info.n_child_records = (int64_t)flat.records.size();
@@ -1139,14 +1163,23 @@ void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();  // a call without stats may have left its tail on a stream
-    if (s->arena.owned && s->arena.base) (void)hipFree(s->arena.base);
-    if (s->h_counters) (void)hipHostFree(s->h_counters);
+    for (Lane& ln : s->lanes) {
+        if (ln.arena.owned && ln.arena.base) (void)hipFree(ln.arena.base);
+        if (ln.h_counters) (void)hipHostFree(ln.h_counters);
+        if (ln.ev_ok) {
+            for (auto& e : ln.ev_snap) if (e) (void)hipEventDestroy(e);
+            for (auto& e : ln.ev_frame) if (e) (void)hipEventDestroy(e);
+            if (ln.ev_join) (void)hipEventDestroy(ln.ev_join);
+        }
+        for (auto& e : ln.ev_pool) (void)hipEventDestroy(e);
+        if (ln.stream) (void)hipStreamDestroy(ln.stream);
+    }
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    for (auto& e : s->ev_wall) if (e) (void)hipEventDestroy(e);
     void* ptrs[] = {s->d_recs, s->d_qblocks, s->d_prims, s->d_tprims, s->d_prim_ids, s->d_mats, s->d_texs, s->d_lights};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : s->d_tex_pixels) (void)hipFree(p);
     for (DevBuf* b : {&s->accum, &s->rgba, &s->probe_in, &s->probe_out, &s->probe_out2}) b->release();
-    if (s->ev_ok) { for (auto& e : s->ev_snap) (void)hipEventDestroy(e); for (auto& e : s->ev_frame) (void)hipEventDestroy(e); }
-    for (auto& e : s->ev_pool) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -1226,36 +1259,38 @@ static int plan_render(const rt_scene* s, const rt_image_spec* spec, const rt_pa
 // after k_shade: it tells the host how long the next queue is while the device works on this bounce's shadow rays,
 // so the stream never drains inside a call.  Every kernel reads its queue length from device memory; the host's
 // numbers only size the grids (upper bounds: a queue never outgrows the one it came from).
-static int run_render(rt_scene* s, Arena& arena, const rt_image_spec* spec, const RenderPlan& P, float* d_accum, hipStream_t stream,
-                      rt_stats* stats, bool may_create_events) {
+// Of the pixel batches (in loop order) this call takes those with index % n_lanes == lane_i.
+static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* spec, const RenderPlan& P, float* d_accum, hipStream_t stream,
+                      rt_stats* stats, bool may_create_events, int lane_i = 0, int n_lanes = 1) {
     const int W = spec->width, H = spec->height, D = spec->ray_tracing_max_depth, reps = spec->soft_shadow_monte_carlo_repetitions;
     const int L = s->d.n_pos_lights;
     Work& wk = arena.wk;
     rt_stats st{};
     st.ms_build = s->ms_build;
     const size_t n_ctr = (size_t)(3 * D + 8);
-    if (n_ctr > s->h_counter_words) return fail(RT_ERR_LIMIT, "RayTracingMaxDepth exceeds the counter snapshots of this scene");
+    if (n_ctr > ln.h_counter_words) return fail(RT_ERR_LIMIT, "RayTracingMaxDepth exceeds the counter snapshots of this scene");
     const bool timed = stats != nullptr;
     const bool staged = timed && may_create_events;  // per-stage events (and their host-side list) only where the entry point may allocate
     size_t ev_used = 0;
     auto stamp = [&]() -> int {  // one timing event on the stream, from the pool (grown only where the entry point may allocate)
-        if (ev_used == s->ev_pool.size()) {
+        if (ev_used == ln.ev_pool.size()) {
             if (!may_create_events) return -1;
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return -1;
-            s->ev_pool.push_back(e);
+            ln.ev_pool.push_back(e);
         }
-        if (hipEventRecord(s->ev_pool[ev_used], stream) != hipSuccess) return -1;
+        if (hipEventRecord(ln.ev_pool[ev_used], stream) != hipSuccess) return -1;
         return (int)ev_used++;
     };
     struct Span { int a, b; int kind; };  // kind 0 = k_extend, 1 = k_shadow
     std::vector<Span> spans;
-    if (timed) HIP_TRY(hipEventRecord(s->ev_frame[0], stream));
+    if (timed) HIP_TRY(hipEventRecord(ln.ev_frame[0], stream));
     HIP_TRY(hipMemsetAsync(wk.frame_counters, 0, 4 * sizeof(unsigned long long), stream));
     const DCamera cam = make_camera(s, W, H);
     for (int s0 = P.sA; s0 < P.sB; s0 += P.ns_max) {
         const int ns = std::min(P.ns_max, P.sB - s0);
         for (long long lp0 = 0; lp0 < P.n_local_pixels; lp0 += P.pix_per_batch) {
+            if ((int)((lp0 / P.pix_per_batch) % n_lanes) != lane_i) continue;
             Batch B{};
             B.W = W; B.H = H; B.tile = P.tile; B.tiles_x = P.tiles_x;
             B.rank = P.part.rank; B.world = P.part.world_size; B.by_tiles = P.by_tiles ? 1 : 0;
@@ -1276,9 +1311,9 @@ static int run_render(rt_scene* s, Arena& arena, const rt_image_spec* spec, cons
                 hipLaunchKernelGGL(k_extend, dim3(grid_for(bound, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, wk, q, n_rays);
                 if (staged) se.b = stamp();
                 hipLaunchKernelGGL(k_shade, dim3((bound + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, B, wk, q, n_rays, qn, b);
-                uint32_t* snap = s->h_counters + (size_t)(b & 1) * s->h_counter_words;
+                uint32_t* snap = ln.h_counters + (size_t)(b & 1) * ln.h_counter_words;
                 HIP_TRY(hipMemcpyAsync(snap, wk.counters, n_ctr * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipEventRecord(s->ev_snap[b & 1], stream));
+                HIP_TRY(hipEventRecord(ln.ev_snap[b & 1], stream));
                 // the PhongBlinn hits of this bounce (at most `bound`): pairs, shadow rays, shading
                 if (L > 0) {
                     const unsigned long long n_pairs = (unsigned long long)bound * L;
@@ -1297,7 +1332,7 @@ static int run_render(rt_scene* s, Arena& arena, const rt_image_spec* spec, cons
                 hipLaunchKernelGGL(k_phong, dim3((bound + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, B, wk, n_phong);
                 if (staged) { spans.push_back(se); spans.push_back(ss); }
                 // how long are this bounce's queues?  (the device is busy with the kernels above meanwhile)
-                HIP_TRY(hipEventSynchronize(s->ev_snap[b & 1]));
+                HIP_TRY(hipEventSynchronize(ln.ev_snap[b & 1]));
                 const uint32_t nq = snap[b], np = snap[D + 1 + b];
                 if (b == 0) { st.paths += nq; st.rays_primary += nq; } else st.rays_continuation += nq;
                 st.phong_hits += np;
@@ -1309,18 +1344,18 @@ static int run_render(rt_scene* s, Arena& arena, const rt_image_spec* spec, cons
     }
     HIP_TRY(hipGetLastError());
     if (stats) {
-        unsigned long long* fc = reinterpret_cast<unsigned long long*>(s->h_counters + 2 * s->h_counter_words);
+        unsigned long long* fc = reinterpret_cast<unsigned long long*>(ln.h_counters + 2 * ln.h_counter_words);
         HIP_TRY(hipMemcpyAsync(fc, wk.frame_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipEventRecord(s->ev_frame[1], stream));
-        HIP_TRY(hipEventSynchronize(s->ev_frame[1]));
+        HIP_TRY(hipEventRecord(ln.ev_frame[1], stream));
+        HIP_TRY(hipEventSynchronize(ln.ev_frame[1]));
         st.rays_shadow = fc[0];
         float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, s->ev_frame[0], s->ev_frame[1]));
+        HIP_TRY(hipEventElapsedTime(&ms, ln.ev_frame[0], ln.ev_frame[1]));
         st.ms_render = ms;
         for (const Span& sp : spans) {
             if (sp.a < 0 || sp.b < 0) continue;
             float t = 0;
-            if (hipEventElapsedTime(&t, s->ev_pool[(size_t)sp.a], s->ev_pool[(size_t)sp.b]) != hipSuccess) continue;
+            if (hipEventElapsedTime(&t, ln.ev_pool[(size_t)sp.a], ln.ev_pool[(size_t)sp.b]) != hipSuccess) continue;
             (sp.kind == 0 ? st.ms_extend : st.ms_shadow) += t;
         }
         st.ms_shade = st.ms_render - st.ms_extend - st.ms_shadow;  // everything else between the first and the last launch
@@ -1340,11 +1375,57 @@ static int rt_render_accum_device_impl(rt_scene* s, const rt_image_spec* spec, c
         if (stats) { *stats = rt_stats{}; stats->ms_build = s->ms_build; }
         return RT_OK;
     }
+    // lanes: RTGO_LANES (1 or 2, default 2) when the share has at least two pixel batches
+    const char* lanes_env = std::getenv("RTGO_LANES");
+    int n_lanes = lanes_env ? std::atoi(lanes_env) : kLanes;
+    n_lanes = n_lanes < 1 ? 1 : (n_lanes > kLanes ? kLanes : n_lanes);
+    const long long n_batches = (P.n_local_pixels + P.pix_per_batch - 1) / P.pix_per_batch;
+    if (n_batches < n_lanes) n_lanes = (int)n_batches;
     // the widest launch is k_shadow's: one lane per (pair, repetition lane), at most 64 lanes per pair
-    rc = ensure_work(s, P.batch_paths, spec->ray_tracing_max_depth, s->d.n_pos_lights,
-                     (unsigned long long)P.batch_paths * (unsigned long long)std::max(1, s->d.n_pos_lights) * 64ull);
-    if (rc != RT_OK) return rc;
-    return run_render(s, s->arena, spec, P, d_accum, (hipStream_t)hip_stream, stats, true);
+    for (int l = 0; l < n_lanes; ++l) {
+        rc = ensure_work(s, s->lanes[l], P.batch_paths, spec->ray_tracing_max_depth, s->d.n_pos_lights,
+                         (unsigned long long)P.batch_paths * (unsigned long long)std::max(1, s->d.n_pos_lights) * 64ull);
+        if (rc != RT_OK) return rc;
+    }
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (n_lanes == 1) return run_render(s, s->lanes[0], s->lanes[0].arena, spec, P, d_accum, stream, stats, true);
+    // fork: the other lanes start behind what the caller has queued on its stream (the zeroing of d_accum, say)
+    if (stats) HIP_TRY(hipEventRecord(s->ev_wall[0], stream));
+    HIP_TRY(hipEventRecord(s->ev_fork, stream));
+    std::vector<rt_stats> part_stats((size_t)n_lanes);
+    const int device = s->device;
+    rc = on_every_rank(n_lanes, [&](int l) -> int {
+        Lane& ln = s->lanes[l];
+        HIP_TRY(hipSetDevice(device));
+        hipStream_t st = l == 0 ? stream : ln.stream;
+        if (l > 0) HIP_TRY(hipStreamWaitEvent(st, s->ev_fork, 0));
+        const int r = run_render(s, ln, ln.arena, spec, P, d_accum, st, stats ? &part_stats[(size_t)l] : nullptr, true, l, n_lanes);
+        if (l > 0 && r == RT_OK) HIP_TRY(hipEventRecord(ln.ev_join, st));
+        return r;
+    });
+    if (rc != RT_OK) {
+        (void)hipDeviceSynchronize();  // nothing of a failed call is left running on the lanes' streams
+        return rc;
+    }
+    // join: what the caller queues next on its stream comes after every lane's batches
+    for (int l = 1; l < n_lanes; ++l) HIP_TRY(hipStreamWaitEvent(stream, s->lanes[l].ev_join, 0));
+    if (stats) {
+        HIP_TRY(hipEventRecord(s->ev_wall[1], stream));
+        HIP_TRY(hipEventSynchronize(s->ev_wall[1]));
+        rt_stats t = part_stats[0];
+        for (int l = 1; l < n_lanes; ++l) {
+            const rt_stats& x = part_stats[(size_t)l];
+            t.paths += x.paths; t.rays_primary += x.rays_primary; t.rays_continuation += x.rays_continuation;
+            t.rays_shadow += x.rays_shadow; t.rays_shadow_reference_equivalent += x.rays_shadow_reference_equivalent;
+            t.phong_hits += x.phong_hits;
+            t.ms_extend += x.ms_extend; t.ms_shadow += x.ms_shadow; t.ms_shade += x.ms_shade;  // stream time, summed over the lanes
+        }
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_wall[0], s->ev_wall[1]));
+        t.ms_render = ms;
+        *stats = t;
+    }
+    return RT_OK;
 }
 
 // rt_render_accum_device for callers that cannot allocate: the batch workspace is this GPU's copy of `scratch`.
@@ -1378,7 +1459,7 @@ static int rt_render_accum_device_static_impl(rt_scene* s, const rt_image_spec* 
     st.paths = P.batch_paths; st.depth = D; st.lpos = L; st.overflow_entries = entries;
     // nothing in the workspace has to survive from an earlier call: run_render zeroes the counters it reads, and
     // every other array is written before it is read
-    return run_render(s, st, spec, P, d_accum, (hipStream_t)hip_stream, stats, false);
+    return run_render(s, s->lanes[0], st, spec, P, d_accum, (hipStream_t)hip_stream, stats, false);
 }
 
 static int rt_resolve_device_impl(const float* d_accum, int32_t width, int32_t height, int32_t spp, uint8_t* d_rgba, void* hip_stream) {
@@ -1443,7 +1524,7 @@ static int rt_trace_rays_impl(rt_scene* s, const float* rays, int64_t n, int32_t
     HIP_TRY(s->probe_out.ensure((size_t)n * sizeof(int)));
     HIP_TRY(s->probe_out2.ensure((size_t)n * sizeof(float)));
     HIP_TRY(hipMemcpy(s->probe_in.p, rays, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_trace_probe, dim3(grid_for((unsigned long long)n, s->arena.grid_cap)), dim3(kBlock), 0, nullptr, s->d, s->arena.wk,
+    hipLaunchKernelGGL(k_trace_probe, dim3(grid_for((unsigned long long)n, s->lanes[0].arena.grid_cap)), dim3(kBlock), 0, nullptr, s->d, s->lanes[0].arena.wk,
                        (const float*)s->probe_in.p, (uint32_t)n, any_hit, (int*)s->probe_out.p, (float*)s->probe_out2.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(prim_out, s->probe_out.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
@@ -1484,7 +1565,7 @@ static int rt_scatter_probe_impl(rt_scene* s, const rt_image_spec* spec, uint64_
     unsigned char* in = (unsigned char*)s->probe_in.p;
     HIP_TRY(hipMemcpy(in, rays, ray_bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(in + align_up(ray_bytes), keys, key_bytes, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_scatter_probe, dim3(grid_for((unsigned long long)n, s->arena.grid_cap)), dim3(kBlock), 0, nullptr, s->d, s->arena.wk,
+    hipLaunchKernelGGL(k_scatter_probe, dim3(grid_for((unsigned long long)n, s->lanes[0].arena.grid_cap)), dim3(kBlock), 0, nullptr, s->d, s->lanes[0].arena.wk,
                        (const float*)in, (const uint32_t*)(in + align_up(ray_bytes)), (uint32_t)n, (uint32_t)seed, (uint32_t)(seed >> 32),
                        spec->soft_shadow_monte_carlo_repetitions, (float*)s->probe_out.p);
     HIP_TRY(hipGetLastError());
