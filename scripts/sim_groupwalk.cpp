@@ -395,3 +395,55 @@ extern "C" int sim_big_shapes(const orc_scene* s, const rt_image_spec* spec, uin
         }
     return 0;
 }
+
+// Per-ray block visits of every shadow ray, pair by pair (design-time: how uneven are the 64 walks of a wavefront,
+// and would a lane that walks 2 or 4 repetitions of its pair one after the other even them out?).
+// out rows: {light, pixel, n_rays, visits[0..reps)} as int32, reps <= 64.
+extern "C" int64_t sim_ray_visits(const orc_scene* s, const rt_image_spec* spec, uint64_t seed, int32_t* out, int64_t cap_rows, int row_len) {
+    const Scene& sc = s->sc;
+    const int W = spec->width, H = spec->height, reps = spec->soft_shadow_monte_carlo_repetitions;
+    const CameraF64 c64 = new_camera(sc, W, H);
+    const Camera<float> cf = narrow_camera<float>(c64);
+    const Tables<float>& T = sc.t32;
+    int64_t n = 0;
+    for (int row = 0; row < H; ++row)
+        for (int i = 0; i < W; ++i) {
+            const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(row * W + i), 0u};
+            const Ray<float> r = camera_ray(cf, W, H, i, H - 1 - row, key);
+            Hit<float> hit;
+            if (!trace_stack_f32(sc, r, 0.0f, FLT_MAX, false, hit, nullptr)) continue;
+            const Shape<float>& sh = T.shapes[hit.shape];
+            const Material<float>& m = T.materials[sh.material];
+            if (m.kind != RT_MAT_PHONGBLINN) continue;
+            int lpos = -1;
+            for (size_t li = 0; li < T.lights.size(); ++li) {
+                const Light<float>& L = T.lights[li];
+                if (L.kind == RT_LIGHT_AMBIENT) continue;
+                ++lpos;
+                const V3<float> ldir = unit(sub(L.pos, hit.p));
+                const float inten = saturate(dot(hit.normal, ldir));
+                const V3<float> h = unit(add(ldir, r.d));
+                const float si = std::pow(saturate(dot(hit.normal, h)), m.param);
+                if (inten == 0.0f && (si == 0.0f || (m.spec.x == 0 && m.spec.y == 0 && m.spec.z == 0))) continue;
+                if (n >= cap_rows) return -1;
+                int32_t* o = out + n * row_len;
+                o[0] = lpos; o[1] = row * W + i;
+                int nr = 0;
+                for (int k = 0; k < reps && k < row_len - 3; ++k) {
+                    const V3<float> jit = scale(0.25f, random_in_unit_sphere<float>(key, 0, P_SHADOW, (uint32_t)(lpos * reps + k)));
+                    const V3<float> shifted = add(L.pos, jit);
+                    o[3 + k] = -1;
+                    if (L.kind == RT_LIGHT_SPOT && !(dot(L.look_dir, unit(sub(hit.p, shifted))) >= L.cos_angle)) continue;
+                    const V3<float> ld = sub(shifted, hit.p);
+                    const float d = norm(ld);
+                    TraceCounters tc; Hit<float> hh;
+                    (void)trace_stack_f32(sc, Ray<float>{hit.p, scale(1.0f / d, ld)}, 0.01f, d, true, hh, &tc);
+                    o[3 + k] = (int32_t)tc.inner;
+                    ++nr;
+                }
+                o[2] = nr;
+                if (nr > 0) ++n;
+            }
+        }
+    return n;
+}
