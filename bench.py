@@ -162,7 +162,8 @@ def roofline(shadow_s, shadow_rays, world, W, H, spp, bray):
     The candidates are VALU issue and the vector-memory path (TA + vector L1).  Their per-frame work is counted by
     rocprofv3 PMC passes over this same command (profiles/r02/bounds.json: instruction and access counts are
     properties of the workload, identical from run to run for a seed); what each unit sustains per clock comes
-    from the micro-benchmarks of scripts/calib.hip run on the same box (same file).  frac = busy time of the
+    from the micro-benchmarks of scripts/calib.hip and scripts/calib_mix.hip run on the same box (same file).
+    peak (VALU) = the rate at which the SIMDs could issue this kernel's instruction mix.  frac = busy time of the
     busiest unit / the kernel's measured time (HIP events around every k_shadow launch of the timed region).
     A render call runs its batches on two streams (rtgo_hip.hip Lane): in the timed region a k_shadow launch shares
     the GPU with the other lane's HBM-bound kernels (and at times with its k_shadow), so its duration includes the
@@ -180,18 +181,25 @@ def roofline(shadow_s, shadow_rays, world, W, H, spp, bray):
         return out  # the committed counts are per frame of the 1-GPU headline run
     pf, c = b["per_frame"], b["calib"]
     clk = c["clock_hz"]
-    valu_s = pf["valu_insts"] * c["valu_cycles_per_wave_inst_per_simd"] / (c["simds"] * clk)
+    # VALU: instructions by class (SQ_INSTS_VALU_* of a PMC pass) x the SIMD cycles an instruction of that class takes
+    # (scripts/calib_mix.hip on the same box).  A class holds cheap and dear instructions (a v_mov takes 2.6 cycles, a
+    # v_cndmask 4.3; both count as "other"), so the busy time is a bracket: its lower end, every class at its cheapest
+    # instruction, is what frac reports.
+    lo = sum(pf["valu_mix"][k] * c["valu_class_cycles"][k][0] for k in pf["valu_mix"])
+    hi = sum(pf["valu_mix"][k] * c["valu_class_cycles"][k][1] for k in pf["valu_mix"])
+    valu_s, valu_s_hi = lo / (c["simds"] * clk), hi / (c["simds"] * clk)
     hits = pf["tcp_accesses"] - pf["tcp_l2_read_req"]
     ta_s = (hits / c["tcp_l1_hit_accesses_per_clk_per_cu"] + pf["tcp_l2_read_req"] / c["tcp_l2_served_accesses_per_clk_per_cu"]) / (c["cus"] * clk)
     hbm_bytes = 2 * pf["hbm_fetch_bytes"] + pf["hbm_write_bytes"]  # gfx950 FETCH_SIZE counts half the bytes (guide, HBM section)
     fr = {"valu_issue": valu_s / shadow_s, "ta_l1": ta_s / shadow_s, "hbm": hbm_bytes / shadow_s / (HBM_PEAK_GBS * 1e9)}
     bound = max(fr, key=fr.get)
     if bound == "valu_issue":
-        out.update(achieved=pf["valu_insts"] / shadow_s / 1e9, peak=c["simds"] * clk / c["valu_cycles_per_wave_inst_per_simd"] / 1e9, unit="G wave64-inst/s")
+        out.update(achieved=pf["valu_insts"] / shadow_s / 1e9, peak=pf["valu_insts"] / valu_s / 1e9, unit="G wave64-inst/s")
     elif bound == "ta_l1":
         out.update(achieved=pf["tcp_accesses"] / shadow_s / 1e9, peak=pf["tcp_accesses"] / ta_s / 1e9, unit="G L1-access/s")
     else:
         out.update(achieved=hbm_bytes / shadow_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+    fr["valu_issue_if_every_class_cost_its_dearest_instruction"] = valu_s_hi / shadow_s
     out.update(bound=bound, frac=fr[bound], traffic=hbm_bytes / b["launches_per_frame"], fractions=fr,
                ta_busy_frac_profiled=pf.get("ta_busy_frac"), source="profiles/r02/bounds.json")
     return out
