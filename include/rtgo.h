@@ -186,7 +186,10 @@ int rt_render(rt_scene* scene, const rt_image_spec* spec, const rt_partition* pa
  * the queue lengths (on an event recorded before that bounce's shadow rays, so the stream
  * itself never drains).  With stats != NULL it returns when the frame is complete; with
  * stats == NULL it returns once the last batch is enqueued, its tail still running on the
- * stream. */
+ * stream.  Half of the batches run on a second stream that the scene owns (and a host thread
+ * that lives for the call), forked from hip_stream at the start of the call and joined back
+ * to it at the end: what the caller queued on hip_stream before the call is seen by every
+ * batch, what it queues afterwards comes after all of them (RTGO_LANES=1: one stream). */
 int rt_render_accum_device(rt_scene* scene, const rt_image_spec* spec, const rt_partition* part,
                            float* d_accum_rgb, void* hip_stream, rt_stats* stats);
 
