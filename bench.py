@@ -77,7 +77,7 @@ def main():
     rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     keys = ("rays", "rays_primary", "rays_continuation", "rays_shadow", "rays_shadow_reference_equivalent",
-            "ms_extend", "ms_shadow", "ms_shade", "ms_render")
+            "ms_extend", "ms_shadow", "ms_shade", "ms_render", "rays_shadow_beam")
 
     lib_build = {"s": 0.0}
 
@@ -104,7 +104,7 @@ def main():
             totals[k] += v
     loop.fence()
     elapsed, sums = loop.aggregate(time.perf_counter() - t0, [totals[k] for k in keys] + [one_shot])
-    rays, n_prim, n_cont, n_shadow, n_shadow_ref, ms_extend, ms_shadow, ms_shade, _ms_render, one_shot_sum = sums
+    rays, n_prim, n_cont, n_shadow, n_shadow_ref, ms_extend, ms_shadow, ms_shade, _ms_render, n_beam, one_shot_sum = sums
     # after the timed region: this rank's share once more on ONE lane (RTGO_LANES=1), where no other kernel runs
     # beside k_shadow, so its launch durations are those of the kernel alone (roofline["alone"])
     os.environ["RTGO_LANES"] = "1"
@@ -134,7 +134,8 @@ def main():
                        "tree_depth": info["tree_depth"], "partition": "samples" if world > 1 else "all",
                        "real_stl": bool(os.environ.get("RTGO_DRAGON_STL"))},
             "rays_per_frame": {"primary": n_prim / args.steps, "continuation": n_cont / args.steps,
-                               "shadow": n_shadow / args.steps, "shadow_reference_equivalent": n_shadow_ref / args.steps},
+                               "shadow": n_shadow / args.steps, "of_which_decided_by_pair_beams": n_beam / args.steps,
+                               "shadow_reference_equivalent": n_shadow_ref / args.steps},
             "kernel_ms_per_frame": {"k_extend": ms_extend / args.steps / world, "k_shadow": ms_shadow / args.steps / world,
                                     "shade_phong_other": ms_shade / args.steps / world},
             "roofline": roofline(shadow_s, n_shadow / args.steps / world, world, W, H, spec.AntiAliasingFactor, bray),

@@ -132,7 +132,9 @@ typedef struct rt_share {       /* what one rank of a partition renders (rt_part
 typedef struct rt_stats {
     uint64_t rays_primary;       /* closest-hit traversals at bounce 0                 */
     uint64_t rays_continuation;  /* closest-hit traversals at bounce > 0               */
-    uint64_t rays_shadow;        /* any-hit traversals actually launched               */
+    uint64_t rays_shadow;        /* shadow rays whose visibility the device decided: traced one by one, or proven
+                                    unoccluded together with the other repetitions of their (hit, light) pair by one
+                                    conservative walk (rays_shadow_beam of them)                                  */
     uint64_t rays_shadow_reference_equivalent; /* incl. the ones the reference traces
                                     before its spot-cone test, light.go:124            */
     uint64_t phong_hits;
@@ -143,6 +145,7 @@ typedef struct rt_stats {
                                     k_shadow, and the rest of each stream's span.  A render call runs its batches on
                                     two streams that overlap (RTGO_LANES=1: one), the stage times are summed over
                                     them, so the three can add up to more than ms_render.                        */
+    uint64_t rays_shadow_beam;   /* of rays_shadow: decided by a pair's beam walk, never generated as rays */
 } rt_stats;
 
 typedef struct rt_scene_info {

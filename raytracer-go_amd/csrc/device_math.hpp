@@ -392,6 +392,108 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
     return best_prim >= 0;
 }
 
+// ---- one conservative walk for all the shadow rays of a (hit, light) pair ------------------------------------
+// Every jittered light position of a pair lies in the cube of half-width R around the light (light.go:94: the light
+// moved by 0.25 * randomInUnitSphere), so every shadow ray of the pair lies in the beam
+//     { p + s (D + j) : s0 <= s <= s1, |j_a| <= R },   D = light - p.
+// At parameter s the beam spans [p_a + s (D_a - R), p_a + s (D_a + R)] on axis a; it meets a box's slab there iff
+// s (D_a - R) <= hi_a - p_a and s (D_a + R) >= lo_a - p_a, two half-lines in s.  With both coefficients positive the
+// second bounds s from below through the LOWER plane and the first from above through the upper plane — a ray's slab
+// test with different divisors for entry and exit; both negative: the planes swap roles; of different sign (the beam
+// straddles the axis): both bound s from below, one is kept, and nothing bounds it from above.  If the bounds of the
+// three axes and [s0, s1] leave no s, no ray of the pair meets the box.  A walk over the EXACT boxes that meets no leaf
+// proves every ray of the pair unoccluded (shapes lie inside their leaves' exact boxes; the quantised boxes of the
+// per-ray walk are only larger); it stops at the first leaf box met, and the pair's rays are then traced one by one.
+// R, s0 and s1 carry margins far above float32 rounding.  (CPU simulation on config 3, scripts/sim_groupwalk.cpp
+// sim_ball_beam: 55 % of the pairs are proven clear by 4.7 block visits each; the others give up after 8.9.)
+struct Beam {
+    f3 inv_n, c_n, inv_f, c_f;  // entry bound = near plane * inv_n + c_n, exit bound = far plane * inv_f + c_f
+    uint32_t sign;              // bit a: the near plane on axis a is the UPPER one
+    float s0, s1;
+};
+RT_DEV Beam make_beam(f3 p, f3 light, float R, float tmin) {
+    Beam b;
+    const float D[3] = {light.x - p.x, light.y - p.y, light.z - p.z}, P[3] = {p.x, p.y, p.z};
+    float in[3], cn[3], jf[3], cf[3];
+    b.sign = 0u;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float c1 = D[a] - R, c2 = D[a] + R;
+        const float inf = __builtin_inff();
+        if (c1 > 0.0f) {            // entry through the lower plane (divisor c2), exit through the upper (c1)
+            in[a] = 1.0f / c2; jf[a] = 1.0f / c1; cf[a] = -P[a] * jf[a];
+        } else if (c2 < 0.0f) {     // entry through the upper plane (divisor c1), exit through the lower (c2)
+            in[a] = 1.0f / c1; jf[a] = 1.0f / c2; cf[a] = -P[a] * jf[a];
+            b.sign |= 1u << a;
+        } else {                    // straddles: one of the two lower bounds, no upper bound
+            if (D[a] < 0.0f) { in[a] = 1.0f / c1; b.sign |= 1u << a; } else in[a] = 1.0f / c2;
+            jf[a] = 0.0f; cf[a] = inf;
+        }
+        cn[a] = -P[a] * in[a];
+    }
+    b.inv_n = mk3(in[0], in[1], in[2]); b.c_n = mk3(cn[0], cn[1], cn[2]);
+    b.inv_f = mk3(jf[0], jf[1], jf[2]); b.c_f = mk3(cf[0], cf[1], cf[2]);
+    const float len = sqrtf(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);
+    b.s0 = 0.999f * tmin / (len + 1.7320508f * R);
+    b.s1 = 1.0001f;
+    return b;
+}
+// visit_block() for a beam: bit k of the masks = position k of the order slot = k ^ sign
+RT_DEV void beam_visit_block(const DScene& S, uint32_t cur, const Beam& bm, uint32_t ref[8], uint32_t* leaf_mask, uint32_t* inner_mask) {
+    const uint32_t first = cur >> 8, present = cur & 0xffu;
+    const uint32_t leaves = __float_as_uint(S.recs[2 * (size_t)first + 1].w);
+    const bool nx = (bm.sign & 1u) != 0u, ny = (bm.sign & 2u) != 0u, nz = (bm.sign & 4u) != 0u;
+    uint32_t hit = 0;
+#pragma unroll
+    for (int h = 0; h < 8; h += kVisitBatch) {
+        float4 ra[kVisitBatch], rb[kVisitBatch];
+#pragma unroll
+        for (int k = 0; k < kVisitBatch; ++k) {
+            const uint32_t oct = (uint32_t)(h + k) ^ bm.sign;
+            const size_t idx = (size_t)first + (uint32_t)__popc(present & ((1u << oct) - 1u));
+            ra[k] = S.recs[2 * idx];
+            rb[k] = S.recs[2 * idx + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < kVisitBatch; ++k) {
+            const float4 a = ra[k], b = rb[k];  // {min.xyz, max.x}, {max.y, max.z, w0, w1}
+            // a NaN (0 * inf, inf - inf) drops out of fmaxf / fminf: that bound then culls nothing
+            const float ex = fmaf(nx ? a.w : a.x, bm.inv_n.x, bm.c_n.x), xx = fmaf(nx ? a.x : a.w, bm.inv_f.x, bm.c_f.x);
+            const float ey = fmaf(ny ? b.x : a.y, bm.inv_n.y, bm.c_n.y), xy = fmaf(ny ? a.y : b.x, bm.inv_f.y, bm.c_f.y);
+            const float ez = fmaf(nz ? b.y : a.z, bm.inv_n.z, bm.c_n.z), xz = fmaf(nz ? a.z : b.y, bm.inv_f.z, bm.c_f.z);
+            const float lo = fmaxf(fmaxf(ex, ey), fmaxf(ez, bm.s0));
+            const float hi = fminf(fminf(xx, xy), fminf(xz, bm.s1));
+            hit |= lo <= hi ? (1u << (h + k)) : 0u;
+            ref[h + k] = __float_as_uint(b.z);
+        }
+        asm volatile("" ::: "memory");
+    }
+    uint32_t m = present | ((leaves & 0xffu) << 8);
+    const uint32_t s4 = bm.sign & 4u, s2 = bm.sign & 2u, s1 = bm.sign & 1u;
+    m = ((m >> s4) & 0x0f0fu) | ((m << s4) & 0xf0f0u);
+    m = ((m >> s2) & 0x3333u) | ((m << s2) & 0xccccu);
+    m = ((m >> s1) & 0x5555u) | ((m << s1) & 0xaaaau);
+    hit &= m;
+    *leaf_mask = hit & (m >> 8);
+    *inner_mask = hit & ~(m >> 8);
+}
+// true: no leaf box of the tree meets the beam.  Every lane of the wavefront calls it (live = this lane has a beam).
+RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, const Beam& bm) {
+    uint32_t cur = S.root_ref;
+    int sp = 0;
+    bool walking = live, clear = true;
+    while (__ballot(walking) != 0ull) {
+        if (walking) {
+            uint32_t ref[8];
+            uint32_t leaf_mask = 0, inner_mask = 0;
+            beam_visit_block(S, cur, bm, ref, &leaf_mask, &inner_mask);
+            if (leaf_mask) { clear = false; walking = false; }
+            else walking = next_block(st, ref, inner_mask, &cur, &sp);
+        }
+    }
+    return clear;
+}
+
 // ---- the shadow-ray walk over quantised blocks ------------------------------------------------
 // k_shadow is bound by the vector-memory path (TA busy 77-90 %, about one L1 access per clock and CU,
 // profiles/r02): a visit of the exact blocks issues 17 loads of 16 bytes per lane.  A shadow ray only asks

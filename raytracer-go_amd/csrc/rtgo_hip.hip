@@ -94,10 +94,10 @@ struct Work {
     uint32_t* vis;   // visible-repetition count per (phong hit, positional light)
     uint32_t* pairs; // (hit, light) pairs whose shading term is not exactly zero: light * n_hits + hit, light-major
     uint32_t* pair_seg;    // the same before compaction: light l's hits at [l * n_hits, l * n_hits + light_count[l])
-    uint32_t* light_count; // [0, L) pairs per positional light, [L, 2L) their exclusive prefix sums
+    uint32_t* light_count; // [0, L) pairs per positional light, [L, 2L) their exclusive prefix sums, [2L] pairs k_pair_beam passes on
     uint32_t* counters;  // per batch: [0..D] ray-queue sizes per bounce, [D+1..2D] phong-queue sizes,
                          // [2D+4..3D+3] pair-queue sizes per bounce
-    unsigned long long* frame_counters;  // per call: [0] shadow rays traced
+    unsigned long long* frame_counters;  // per call: [0] shadow rays traced, [1] shadow rays decided by a pair's beam walk
     uint32_t* overflow;  // traversal stack spill
     uint32_t overflow_stride;
 };
@@ -328,6 +328,21 @@ RT_DEV bool surely_outside_cone(const DLight& L, const f3& p) {
     return cos_p < cos_limit - 1e-4f;
 }
 
+// True only if the spot-cone test passes for EVERY jittered light position (the same bound on the turn of the direction
+// light -> p as above): such a pair traces all of its repetitions.  Only cones up to 90 degrees off the axis are judged.
+RT_DEV bool surely_inside_cone(const DLight& L, const f3& p) {
+    if (L.kind != RT_LIGHT_SPOT) return true;
+    const f3 v = sub3(p, ld3(L.pos));
+    const float dist = norm3(v);
+    const float sin_d = 0.25f / dist * 1.001f + 1e-4f;
+    if (!(sin_d < 0.99f)) return false;
+    const float cos_d = sqrtf(1.0f - sin_d * sin_d);
+    const float cos_p = dot3(ld3(L.look_dir), scale3(1.0f / dist, v));
+    if (!(cos_p > 0.0f)) return false;  // also NaN
+    const float sin_p = sqrtf(fmaxf(0.0f, 1.0f - cos_p * cos_p));
+    return cos_p * cos_d - sin_p * sin_d > L.cos_angle + 1e-4f;  // cos(angle + delta) > cos(Angle)
+}
+
 // One lane per PhongBlinn hit.  A (hit, light) pair whose shading term is exactly (0,0,0) — light behind
 // the surface and no specular lobe towards it — adds count/reps * 0 whatever its soft-shadow rays would
 // find, so those rays are never generated; nor are those of a pair that lies outside a spot light's cone
@@ -364,6 +379,7 @@ __global__ void k_pair_offsets(Work Wk, int n_pos_lights, uint32_t* pair_counter
         run += Wk.light_count[l];
     }
     *pair_counter = run;
+    Wk.light_count[2 * n_pos_lights] = 0u;  // length of the queue k_pair_beam builds
 }
 __global__ __launch_bounds__(kBlock) void k_pair_compact(Work Wk, const uint32_t* n_hits_ptr, int n_pos_lights) {
     const unsigned long long idx = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
@@ -374,6 +390,53 @@ __global__ __launch_bounds__(kBlock) void k_pair_compact(Work Wk, const uint32_t
     if (j < Wk.light_count[l]) Wk.pairs[Wk.light_count[n_pos_lights + l] + j] = l * n_hits + Wk.pair_seg[idx];
 }
 
+// One lane per queued (hit, light) pair: ONE conservative walk for all of the pair's shadow rays (device_math.hpp
+// Beam).  A pair whose beam meets no leaf box, and that lies inside the spot cone for every jittered light position, has
+// all `reps` repetitions visible: its count is written here and none of its rays is generated.  The other pairs go on
+// to k_shadow through a second queue (the space of pair_seg, which k_pair_compact has consumed).
+__global__ __launch_bounds__(kBlock) void k_pair_beam(DScene S, Batch B, Work Wk, const uint32_t* n_hits_ptr, const uint32_t* pair_counter) {
+    __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
+    const uint32_t n_hits = *n_hits_ptr;
+    const uint32_t n_pairs = *pair_counter;
+    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t gstride = gridDim.x * kBlock;
+    const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride, nullptr};
+    uint32_t* const out_counter = Wk.light_count + 2 * S.n_pos_lights;
+    unsigned long long decided = 0;
+    const uint32_t rounds = (n_pairs + gstride - 1) / gstride;  // the same for every thread: block_push is a block-wide operation
+    for (uint32_t it = 0; it < rounds; ++it) {
+        const uint32_t i = it * gstride + gtid;
+        const bool live = i < n_pairs;
+        uint32_t hl = 0, lp = 0, hit_i = 0;
+        bool judge = false;
+        Beam bm{};
+        if (live) {
+            hl = Wk.pairs[i];
+            lp = hl / n_hits;
+            hit_i = hl - lp * n_hits;
+            const uint32_t slot = Wk.phong_queue[hit_i];
+            const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
+            const f3 p = add3(mk3(ro.x, ro.y, ro.z), scale3(ro.w, mk3(rdv.x, rdv.y, rdv.z)));
+            int q = 0;  // positional light #lp
+            for (int seen = -1; q < S.n_lights; ++q)
+                if (S.lights[q].kind != RT_LIGHT_AMBIENT && ++seen == (int)lp) break;
+            const DLight& L = S.lights[q];
+            judge = surely_inside_cone(L, p);
+            if (judge) bm = make_beam(p, ld3(L.pos), 0.25f * 1.0001f + 1e-5f, 0.01f);
+        }
+        const bool clear = beam_is_clear(S, st, judge, bm) && judge;
+        if (clear) {
+            Wk.vis[(size_t)hit_i * S.n_pos_lights + lp] = (uint32_t)B.reps;
+            decided += (unsigned long long)B.reps;
+        }
+        const bool keep = live && !clear;
+        const uint32_t at = block_push(out_counter, keep);
+        if (keep) Wk.pair_seg[at] = hl;
+    }
+    for (int off = 32; off > 0; off >>= 1) decided += __shfl_down(decided, off);
+    if (__lane_id() == 0 && decided) atomicAdd(Wk.frame_counters + 1, decided);
+}
+
 // One lane per (PhongBlinn hit, positional light, repetition lane).  group = lanes per (hit, light):
 // a power of two <= 64; each lane runs repetitions r, r+group, ...  The visible repetitions of a
 // (hit, light) are counted with a ballot popcount: integer, so the result has no summation order.
@@ -381,7 +444,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_compact(Work Wk, const uint32_t
 #define RTGO_SHADOW_WAVES 6  // k_shadow ms per frame at config 3 (quantised walk): 5 waves (LDS stack 20) 416, 6 (15) 395, 7 (11) 392, 8 (8) 404
 #endif
 __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, Batch B, Work Wk, const uint32_t* n_hits_ptr, int bounce,
-                                                   int group, int group_shift, const uint32_t* pair_counter) {
+                                                   int group, int group_shift, const uint32_t* pairs, const uint32_t* pair_counter) {
     __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
     const uint32_t n_hits = *n_hits_ptr;
     __shared__ uint32_t s_wave[(kBlock / 64) * 128];
@@ -401,7 +464,7 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
         // the pair queue is light-major: the lane groups of a wavefront are consecutive hits (neighbouring
         // pixels / samples) towards the SAME light, so all 64 shadow rays are nearly parallel
         const uint32_t r = (uint32_t)(idx & (unsigned long long)(group - 1));
-        const uint32_t hl = active ? Wk.pairs[idx >> group_shift] : 0u;
+        const uint32_t hl = active ? pairs[idx >> group_shift] : 0u;
         const uint32_t lp = hl / n_hits;
         const uint32_t hit_i = hl - lp * n_hits;
         uint32_t count = 0;
@@ -758,7 +821,7 @@ size_t carve_work(Work* w, unsigned char* base, int64_t paths, int depth, int lp
     w->vis = (uint32_t*)take(P * L * sizeof(uint32_t));
     w->pairs = (uint32_t*)take(P * L * sizeof(uint32_t));
     w->pair_seg = (uint32_t*)take(P * L * sizeof(uint32_t));
-    w->light_count = (uint32_t*)take(2 * L * sizeof(uint32_t));
+    w->light_count = (uint32_t*)take((2 * L + 2) * sizeof(uint32_t));
     w->counters = (uint32_t*)take((size_t)(3 * depth + 8) * sizeof(uint32_t));
     w->frame_counters = (unsigned long long*)take(4 * sizeof(unsigned long long));
     w->overflow = (uint32_t*)take((size_t)overflow_entries * sizeof(uint32_t));
@@ -1270,6 +1333,8 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
     const size_t n_ctr = (size_t)(3 * D + 8);
     if (n_ctr > ln.h_counter_words) return fail(RT_ERR_LIMIT, "RayTracingMaxDepth exceeds the counter snapshots of this scene");
     const bool timed = stats != nullptr;
+    const char* beam_env = std::getenv("RTGO_BEAM");  // "0": every pair's rays are traced one by one (A/B switch)
+    const bool beams = !(beam_env && beam_env[0] == '0');
     const bool staged = timed && may_create_events;  // per-stage events (and their host-side list) only where the entry point may allocate
     size_t ev_used = 0;
     auto stamp = [&]() -> int {  // one timing event on the stream, from the pool (grown only where the entry point may allocate)
@@ -1323,9 +1388,16 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
                     hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(64), 0, stream, wk, L, pair_counter);
                     hipLaunchKernelGGL(k_pair_compact, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, wk, n_phong, L);
                     if (reps > 0) {
+                        const uint32_t* queue = wk.pairs;
+                        const uint32_t* queue_len = pair_counter;
+                        if (beams) {  // pairs whose rays one conservative walk proves unoccluded never reach k_shadow
+                            hipLaunchKernelGGL(k_pair_beam, dim3(grid_for(n_pairs, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, B, wk, n_phong, pair_counter);
+                            queue = wk.pair_seg;
+                            queue_len = wk.light_count + 2 * L;
+                        }
                         if (staged) ss.a = stamp();  // ms_shadow brackets k_shadow alone
                         hipLaunchKernelGGL(k_shadow, dim3(grid_for(n_pairs * P.group, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, B, wk, n_phong, b,
-                                           P.group, P.group_shift, pair_counter);
+                                           P.group, P.group_shift, queue, queue_len);
                         if (staged) ss.b = stamp();
                     }
                 }
@@ -1345,10 +1417,11 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
     HIP_TRY(hipGetLastError());
     if (stats) {
         unsigned long long* fc = reinterpret_cast<unsigned long long*>(ln.h_counters + 2 * ln.h_counter_words);
-        HIP_TRY(hipMemcpyAsync(fc, wk.frame_counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(fc, wk.frame_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipEventRecord(ln.ev_frame[1], stream));
         HIP_TRY(hipEventSynchronize(ln.ev_frame[1]));
-        st.rays_shadow = fc[0];
+        st.rays_shadow = fc[0] + fc[1];
+        st.rays_shadow_beam = fc[1];
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ln.ev_frame[0], ln.ev_frame[1]));
         st.ms_render = ms;
@@ -1416,7 +1489,7 @@ static int rt_render_accum_device_impl(rt_scene* s, const rt_image_spec* spec, c
         for (int l = 1; l < n_lanes; ++l) {
             const rt_stats& x = part_stats[(size_t)l];
             t.paths += x.paths; t.rays_primary += x.rays_primary; t.rays_continuation += x.rays_continuation;
-            t.rays_shadow += x.rays_shadow; t.rays_shadow_reference_equivalent += x.rays_shadow_reference_equivalent;
+            t.rays_shadow += x.rays_shadow; t.rays_shadow_beam += x.rays_shadow_beam; t.rays_shadow_reference_equivalent += x.rays_shadow_reference_equivalent;
             t.phong_hits += x.phong_hits;
             t.ms_extend += x.ms_extend; t.ms_shadow += x.ms_shadow; t.ms_shade += x.ms_shade;  // stream time, summed over the lanes
         }
@@ -1690,7 +1763,7 @@ static int rt_multi_render_impl(rt_multi* m, const rt_image_spec* spec, int32_t 
     if (stats) {
         rt_stats t{};
         for (const rt_stats& x : st) {
-            t.rays_primary += x.rays_primary; t.rays_continuation += x.rays_continuation; t.rays_shadow += x.rays_shadow;
+            t.rays_primary += x.rays_primary; t.rays_continuation += x.rays_continuation; t.rays_shadow += x.rays_shadow; t.rays_shadow_beam += x.rays_shadow_beam;
             t.rays_shadow_reference_equivalent += x.rays_shadow_reference_equivalent; t.phong_hits += x.phong_hits; t.paths += x.paths;
             t.ms_build = std::max(t.ms_build, x.ms_build); t.ms_render = std::max(t.ms_render, x.ms_render);
             t.ms_extend = std::max(t.ms_extend, x.ms_extend); t.ms_shadow = std::max(t.ms_shadow, x.ms_shadow); t.ms_shade = std::max(t.ms_shade, x.ms_shade);

@@ -447,3 +447,94 @@ extern "C" int64_t sim_ray_visits(const orc_scene* s, const rt_image_spec* spec,
         }
     return n;
 }
+
+// ---- a pair's shadow rays proven unoccluded by ONE conservative walk -----------------------------------------
+// Every jittered light position lies in the cube of half-width R around the light, so every shadow ray of a (hit,
+// light) pair lies in the "beam" { p + s (D + j) : s in [s0, 1], |j_a| <= R }, D = light - p.  Per axis the beam at
+// parameter s spans [p_a + s (D_a - R), p_a + s (D_a + R)]; it meets a box's slab on that axis iff
+// s (D_a - R) <= hi_a - p_a and s (D_a + R) >= lo_a - p_a: two half-lines in s.  If the intersection over the three
+// axes and [s0, 1] is empty for a box, no ray of the pair meets it.  A walk that meets no LEAF box proves all the
+// pair's rays unoccluded; it stops at the first leaf box it meets (then the pair's rays are traced as today).
+// out: [0] pairs, [1] clear pairs, [2] rays of clear pairs, [3] rays, [4] beam visits of clear pairs, [5] beam visits of
+// the others, [6] per-ray visits of clear pairs' rays, [7] per-ray visits of all rays, [8] clear pairs with an occluded ray (must be 0)
+extern "C" int sim_ball_beam(const orc_scene* s, const rt_image_spec* spec, uint64_t seed, double R, double* out) {
+    const Scene& sc = s->sc;
+    const int W = spec->width, H = spec->height, reps = spec->soft_shadow_monte_carlo_repetitions;
+    const CameraF64 c64 = new_camera(sc, W, H);
+    const Camera<float> cf = narrow_camera<float>(c64);
+    const Tables<float>& T = sc.t32;
+    Node* root = effective(sc.wide_root);
+    for (int i = 0; i < 9; ++i) out[i] = 0;
+    for (int row = 0; row < H; ++row)
+        for (int i = 0; i < W; ++i) {
+            const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(row * W + i), 0u};
+            const Ray<float> r = camera_ray(cf, W, H, i, H - 1 - row, key);
+            Hit<float> hit;
+            if (!trace_stack_f32(sc, r, 0.0f, FLT_MAX, false, hit, nullptr)) continue;
+            const Shape<float>& sh = T.shapes[hit.shape];
+            const Material<float>& m = T.materials[sh.material];
+            if (m.kind != RT_MAT_PHONGBLINN) continue;
+            int lpos = -1;
+            for (size_t li = 0; li < T.lights.size(); ++li) {
+                const Light<float>& L = T.lights[li];
+                if (L.kind == RT_LIGHT_AMBIENT) continue;
+                ++lpos;
+                const V3<float> ldir = unit(sub(L.pos, hit.p));
+                const float inten = saturate(dot(hit.normal, ldir));
+                const V3<float> h = unit(add(ldir, r.d));
+                const float si = std::pow(saturate(dot(hit.normal, h)), m.param);
+                if (inten == 0.0f && (si == 0.0f || (m.spec.x == 0 && m.spec.y == 0 && m.spec.z == 0))) continue;
+                int n_rays = 0, n_occ = 0; double ray_visits = 0;
+                for (int k = 0; k < reps; ++k) {
+                    const V3<float> jit = scale(0.25f, random_in_unit_sphere<float>(key, 0, P_SHADOW, (uint32_t)(lpos * reps + k)));
+                    const V3<float> shifted = add(L.pos, jit);
+                    if (L.kind == RT_LIGHT_SPOT && !(dot(L.look_dir, unit(sub(hit.p, shifted))) >= L.cos_angle)) continue;
+                    const V3<float> ld = sub(shifted, hit.p);
+                    const float d = norm(ld);
+                    TraceCounters tc; Hit<float> hh;
+                    n_occ += trace_stack_f32(sc, Ray<float>{hit.p, scale(1.0f / d, ld)}, 0.01f, d, true, hh, &tc) ? 1 : 0;
+                    ray_visits += (double)tc.inner;
+                    ++n_rays;
+                }
+                if (n_rays == 0) continue;
+                // the beam
+                const double p[3] = {hit.p.x, hit.p.y, hit.p.z};
+                const double D[3] = {L.pos.x - p[0], L.pos.y - p[1], L.pos.z - p[2]};
+                const double len = std::sqrt(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);
+                const double s0 = 0.01 / (len + R * 1.7320508) * 0.999, s1 = 1.0001;
+                const int sign = (D[0] < 0 ? 1 : 0) | (D[1] < 0 ? 2 : 0) | (D[2] < 0 ? 4 : 0);
+                auto meets = [&](const float* lo, const float* hi) {
+                    double a = s0, b = s1;
+                    for (int ax = 0; ax < 3; ++ax) {
+                        const double c1 = D[ax] - R, c2 = D[ax] + R;       // s c1 <= hi - p ; s c2 >= lo - p
+                        const double h1 = (double)hi[ax] - p[ax], l1 = (double)lo[ax] - p[ax];
+                        if (c1 > 0) b = std::min(b, h1 / c1); else if (c1 < 0) a = std::max(a, h1 / c1); else if (h1 < 0) return false;
+                        if (c2 > 0) a = std::max(a, l1 / c2); else if (c2 < 0) b = std::min(b, l1 / c2); else if (l1 > 0) return false;
+                    }
+                    return a <= b;
+                };
+                double visits = 0; bool clear = true;
+                std::vector<Node*> stack;
+                Node* cur = root;
+                if (root->as_leaf) { clear = !meets(root->fmin, root->fmax); cur = nullptr; }
+                while (cur && clear) {
+                    visits += 1;
+                    Node* pending[8]; int np = 0;
+                    for (int k = 0; k < 8 && clear; ++k) {
+                        Node* e = cur->slot[k ^ sign];
+                        if (!e || !meets(e->fmin, e->fmax)) continue;
+                        if (e->as_leaf) clear = false; else pending[np++] = e;
+                    }
+                    if (!clear) break;
+                    for (int q = np - 1; q >= 1; --q) stack.push_back(pending[q]);
+                    if (np > 0) { cur = pending[0]; continue; }
+                    if (stack.empty()) break;
+                    cur = stack.back(); stack.pop_back();
+                }
+                out[0] += 1; out[3] += n_rays; out[7] += ray_visits;
+                if (clear) { out[1] += 1; out[2] += n_rays; out[4] += visits; out[6] += ray_visits; if (n_occ) out[8] += 1; }
+                else out[5] += visits;
+            }
+        }
+    return 0;
+}

@@ -205,3 +205,30 @@ def test_render_lanes_do_not_change_the_frame(backend, rt, c1, monkeypatch):
             for k in ("paths", "rays_primary", "rays_continuation", "rays_shadow", "phong_hits"):
                 assert getattr(s1, k) == getattr(s2, k), k
             assert s1.paths == spec.Width * spec.Height * spp
+
+
+def test_pair_beams_decide_the_same_rays(backend, rt, scenes, c1, gold_dir, monkeypatch):
+    """k_pair_beam proves all the soft-shadow repetitions of a (hit, light) pair unoccluded with one conservative walk
+    (device_math.hpp Beam) and such pairs' rays are never generated.  With RTGO_BEAM=0 every ray is traced: the
+    accumulation buffer and every counter must be identical, and the beams must decide a good part of the rays
+    (README scene: spheres over a floor; config 3: the mesh in its room; config 2 with point-like reps = 1)."""
+    spec1, scene1 = c1
+    spec1 = copy.copy(spec1)
+    spec1.Width, spec1.Height, spec1.AntiAliasingFactor = 200, 120, 4
+    cases = [("config 1", spec1, scene1, 0.05)]
+    spec3, scene3 = scenes.config3(160, 90, 4, 16, asset_dir=gold_dir)
+    cases.append(("config 3", spec3, scene3, 0.2))
+    spec2, scene2 = scenes.config2(160, 90, 2, 1)
+    cases.append(("config 2, one repetition", spec2, scene2, 0.05))
+    for name, spec, scene, least in cases:
+        with backend.DeviceScene(scene) as dev:
+            got, st = dev.render_accum(spec)
+            monkeypatch.setenv("RTGO_BEAM", "0")
+            want, st0 = dev.render_accum(spec)
+            monkeypatch.delenv("RTGO_BEAM")
+        print(f"{name}: {st.rays_shadow_beam} of {st.rays_shadow} shadow rays decided by beams")
+        assert st0.rays_shadow_beam == 0
+        assert np.array_equal(got, want), (name, np.abs(got - want).max())
+        for k in ("paths", "rays_primary", "rays_continuation", "rays_shadow", "phong_hits", "rays_shadow_reference_equivalent"):
+            assert getattr(st, k) == getattr(st0, k), (name, k)
+        assert st.rays_shadow_beam >= least * st.rays_shadow, name
