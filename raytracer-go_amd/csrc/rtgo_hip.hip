@@ -751,8 +751,9 @@ constexpr int kSnapshots = 3;  // pinned copies of the counter block: two altern
 // What one stream of batches needs for itself.  A render call deals its batches out over kLanes lanes, each with a
 // host thread, a stream and a workspace of its own: k_shadow is bound by VALU issue and everything else in a batch
 // by HBM, so one lane's ray generation, nearest-hit walk, shading and accumulation run under the other's shadow
-// rays (config 3: 393 -> 373 ms per frame; with the k_shadow launches of the two lanes made to take turns through
-// events, so that two of them never share the GPU: 381 ms).  A launch's duration now includes the time slices the
+// rays (config 3: 393 -> 373 ms per frame with two lanes; with the k_shadow launches of the two lanes made to take
+// turns through events, so that two of them never share the GPU: 381 ms; with the pair beams in place 2 / 3 / 4 / 6 / 8
+// lanes: 334 / 330 / 325 / 331 / 328 ms over the frame's 16 batches).  A launch's duration now includes the time slices the
 // other lane's kernels got, so the per-kernel times of a two-lane frame add up to more than the frame
 // (RTGO_LANES=1 measures a kernel alone).  A pixel's batches always go to the same lane, in the order of the
 // single-lane loop, so the frame is bit-identical for any number of lanes.
@@ -766,7 +767,7 @@ struct Lane {
     hipStream_t stream = nullptr;     // lanes beyond the first: their own stream (lane 0 runs on the caller's)
     hipEvent_t ev_join = nullptr;
 };
-constexpr int kLanes = 2;
+constexpr int kLanes = 4;
 
 struct rt_scene {
     int device = 0;
@@ -1302,6 +1303,10 @@ static int plan_render(const rt_scene* s, const rt_image_spec* spec, const rt_pa
     while (P->group < reps && P->group < 64) { P->group <<= 1; ++P->group_shift; }
     if (P->empty) return RT_OK;
     int64_t max_paths = part.max_paths_per_batch > 0 ? part.max_paths_per_batch : kDefaultMaxPaths;
+    if (const char* ev = std::getenv("RTGO_MAX_PATHS")) {  // developer knob: log2 of the default batch size
+        const int lg = std::atoi(ev);
+        if (part.max_paths_per_batch <= 0 && lg >= 12 && lg <= 30) max_paths = (int64_t)1 << lg;
+    }
     if (paths_cap > 0 && max_paths > paths_cap) max_paths = paths_cap;
     if (max_paths < (int64_t)tile * tile) {
         if (paths_cap > 0) return fail(RT_ERR_LIMIT, "tile_size^2 paths do not fit the workspace of this entry point; use a smaller tile_size");
@@ -1448,7 +1453,7 @@ static int rt_render_accum_device_impl(rt_scene* s, const rt_image_spec* spec, c
         if (stats) { *stats = rt_stats{}; stats->ms_build = s->ms_build; }
         return RT_OK;
     }
-    // lanes: RTGO_LANES (1 or 2, default 2) when the share has at least two pixel batches
+    // lanes: RTGO_LANES (1 to 4, default 4), at most one per pixel batch of the share
     const char* lanes_env = std::getenv("RTGO_LANES");
     int n_lanes = lanes_env ? std::atoi(lanes_env) : kLanes;
     n_lanes = n_lanes < 1 ? 1 : (n_lanes > kLanes ? kLanes : n_lanes);

@@ -464,7 +464,7 @@ extern "C" int sim_ball_beam(const orc_scene* s, const rt_image_spec* spec, uint
     const Camera<float> cf = narrow_camera<float>(c64);
     const Tables<float>& T = sc.t32;
     Node* root = effective(sc.wide_root);
-    for (int i = 0; i < 9; ++i) out[i] = 0;
+    for (int i = 0; i < 13; ++i) out[i] = 0;
     for (int row = 0; row < H; ++row)
         for (int i = 0; i < W; ++i) {
             const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(row * W + i), 0u};
@@ -514,6 +514,7 @@ extern "C" int sim_ball_beam(const orc_scene* s, const rt_image_spec* spec, uint
                     return a <= b;
                 };
                 double visits = 0; bool clear = true;
+                double prefix = 0; bool single = true;  // visits at the top of the walk with exactly one touched child, an inner one
                 std::vector<Node*> stack;
                 Node* cur = root;
                 if (root->as_leaf) { clear = !meets(root->fmin, root->fmax); cur = nullptr; }
@@ -523,8 +524,21 @@ extern "C" int sim_ball_beam(const orc_scene* s, const rt_image_spec* spec, uint
                     for (int k = 0; k < 8 && clear; ++k) {
                         Node* e = cur->slot[k ^ sign];
                         if (!e || !meets(e->fmin, e->fmax)) continue;
-                        if (e->as_leaf) clear = false; else pending[np++] = e;
+                        if (e->as_leaf) {
+                            if (!std::getenv("SIM_SHAPE_BOXES")) { clear = false; continue; }
+                            // the leaf's box is met: is any of its SHAPES' own boxes?
+                            std::vector<int> group;
+                            subtree_shapes(e, &group);
+                            for (int shape : group) {
+                                V3<double> lo, hi;
+                                shape_bounds(sc.t64.shapes[(size_t)shape], lo, hi);
+                                const float flo[3] = {(float)lo.x - 1e-6f, (float)lo.y - 1e-6f, (float)lo.z - 1e-6f}, fhi[3] = {(float)hi.x + 1e-6f, (float)hi.y + 1e-6f, (float)hi.z + 1e-6f};
+                                out[12] += 1;
+                                if (meets(flo, fhi)) { clear = false; break; }
+                            }
+                        } else pending[np++] = e;
                     }
+                    if (single && clear && np == 1) prefix += 1; else single = false;
                     if (!clear) break;
                     for (int q = np - 1; q >= 1; --q) stack.push_back(pending[q]);
                     if (np > 0) { cur = pending[0]; continue; }
@@ -533,7 +547,7 @@ extern "C" int sim_ball_beam(const orc_scene* s, const rt_image_spec* spec, uint
                 }
                 out[0] += 1; out[3] += n_rays; out[7] += ray_visits;
                 if (clear) { out[1] += 1; out[2] += n_rays; out[4] += visits; out[6] += ray_visits; if (n_occ) out[8] += 1; }
-                else out[5] += visits;
+                else { out[5] += visits; out[9] += prefix; out[10] += ray_visits; out[11] += n_rays; }
             }
         }
     return 0;

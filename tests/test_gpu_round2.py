@@ -182,9 +182,9 @@ def test_multi_device_frame_behind_one_call(backend, rt, c1, hip_buffers):
 
 
 def test_render_lanes_do_not_change_the_frame(backend, rt, c1, monkeypatch):
-    """A render call deals its pixel batches out over two host threads and streams (rtgo_hip.hip Lane); a pixel's
+    """A render call deals its pixel batches out over up to four host threads and streams (rtgo_hip.hip Lane); a pixel's
     batches stay on one lane in the order of the single-lane loop, so the accumulation buffer and the counters are
-    bit-identical for RTGO_LANES=1 and 2: with many small batches, with more than 64 samples (several sample rounds
+    bit-identical for RTGO_LANES=1, 2 and 4: with many small batches, with more than 64 samples (several sample rounds
     per pixel), and with a single batch (one lane has nothing to do)."""
     abi = rt._abi
     spec, scene = c1
@@ -195,15 +195,16 @@ def test_render_lanes_do_not_change_the_frame(backend, rt, c1, monkeypatch):
         for spp, tile, max_paths in cases:
             spec.AntiAliasingFactor = spp
             out = {}
-            for lanes in ("1", "2"):
+            for lanes in ("1", "2", "4"):
                 monkeypatch.setenv("RTGO_LANES", lanes)
                 out[lanes] = dev.render_accum(spec, part=abi.partition(tile_size=tile, max_paths=max_paths))
             monkeypatch.delenv("RTGO_LANES")
             a1, s1 = out["1"]
-            a2, s2 = out["2"]
-            assert np.array_equal(a1, a2), (spp, tile, np.abs(a1 - a2).max())
-            for k in ("paths", "rays_primary", "rays_continuation", "rays_shadow", "phong_hits"):
-                assert getattr(s1, k) == getattr(s2, k), k
+            for lanes in ("2", "4"):
+                a2, s2 = out[lanes]
+                assert np.array_equal(a1, a2), (spp, tile, lanes, np.abs(a1 - a2).max())
+                for k in ("paths", "rays_primary", "rays_continuation", "rays_shadow", "rays_shadow_beam", "phong_hits"):
+                    assert getattr(s1, k) == getattr(s2, k), (k, lanes)
             assert s1.paths == spec.Width * spec.Height * spp
 
 
