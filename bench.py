@@ -10,8 +10,11 @@ of raytracer-go_amd/scenes.py (871,200 triangles) unless RTGO_DRAGON_STL names a
 A step = one whole frame.  At N > 1 the frame's samples are split over the ranks
 (RT_PART_SAMPLES), each rank renders into its own fp32 accumulation buffer in HBM, one RCCL
 reduce(sum) lands the frame on rank 0, which divides and quantises: total work is fixed, so
-"scaling" is "strong".  value = rays traced by all ranks / wall time of the timed region (scene
-already resident in HBM; the timed region ends with the RGBA8 frame in device memory on rank 0).
+"scaling" is "strong".  value = rays whose outcome all ranks determined / wall time of the timed region
+(scene already resident in HBM; the timed region ends with the RGBA8 frame in device memory on rank 0):
+primary and scattered rays + shadow rays, whether a shadow ray was walked through the tree on its own or
+proven unoccluded with the other repetitions of its (hit, light) pair by one conservative beam walk; rays
+the reference traces but whose outcome cannot matter (zero shading term, outside the spot cone) are not counted.
 sec_per_frame_one_shot is what the reference's own clock covers (raytracer.go:69-105): tree build +
 upload + the first frame.
 """
@@ -77,7 +80,7 @@ def main():
     rgba = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     keys = ("rays", "rays_primary", "rays_continuation", "rays_shadow", "rays_shadow_reference_equivalent",
-            "ms_extend", "ms_shadow", "ms_shade", "ms_render", "rays_shadow_beam")
+            "ms_extend", "ms_shadow", "ms_shade", "ms_render", "rays_shadow_beam", "ms_shadow_busy")
 
     lib_build = {"s": 0.0}
 
@@ -104,7 +107,7 @@ def main():
             totals[k] += v
     loop.fence()
     elapsed, sums = loop.aggregate(time.perf_counter() - t0, [totals[k] for k in keys] + [one_shot])
-    rays, n_prim, n_cont, n_shadow, n_shadow_ref, ms_extend, ms_shadow, ms_shade, _ms_render, n_beam, one_shot_sum = sums
+    rays, n_prim, n_cont, n_shadow, n_shadow_ref, ms_extend, ms_shadow, ms_shade, _ms_render, n_beam, ms_shadow_busy, one_shot_sum = sums
     # after the timed region: this rank's share once more on ONE lane (RTGO_LANES=1), where no other kernel runs
     # beside k_shadow, so its launch durations are those of the kernel alone (roofline["alone"])
     os.environ["RTGO_LANES"] = "1"
@@ -115,11 +118,17 @@ def main():
         with open(os.path.join(ROOT, "profiles", "bray.json")) as f:
             bray_all = json.load(f)
         bray = bray_all["config3"]
-        shadow_s = ms_shadow / 1e3 / world / args.steps  # k_shadow seconds per frame (mean over ranks of the summed launch durations)
+        # k_shadow seconds per frame: the time during which k_shadow was running on at least one of the call's streams
+        # (mean over ranks).  The launches of the lanes overlap, so their summed durations (kernel_ms_per_frame) count
+        # the same wall time several times.
+        shadow_s = ms_shadow_busy / 1e3 / world / args.steps
         out = {
             "metric": "Mrays/s (whole node), Stanford Dragon 1080p 64spp",
             "value": rays / elapsed / 1e6,
             "unit": "Mrays/s",
+            # `value` counts every ray whose outcome the device determined; the shadow rays that a pair's beam walk proved
+            # unoccluded (never generated one by one, rays_per_frame.of_which_decided_by_pair_beams) are left out here
+            "value_rays_traced_one_by_one": (rays - n_beam) / elapsed / 1e6,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "sec_per_frame": elapsed / args.steps,
@@ -137,6 +146,7 @@ def main():
                                "shadow": n_shadow / args.steps, "of_which_decided_by_pair_beams": n_beam / args.steps,
                                "shadow_reference_equivalent": n_shadow_ref / args.steps},
             "kernel_ms_per_frame": {"k_extend": ms_extend / args.steps / world, "k_shadow": ms_shadow / args.steps / world,
+                                    "k_shadow_busy": ms_shadow_busy / args.steps / world,
                                     "shade_phong_other": ms_shade / args.steps / world},
             "roofline": roofline(shadow_s, n_shadow / args.steps / world, world, W, H, spec.AntiAliasingFactor, bray),
         }
@@ -145,7 +155,7 @@ def main():
         r1 = roofline(alone["ms_shadow"] / 1e3, alone["rays_shadow"], world, W, H, spec.AntiAliasingFactor, bray)
         out["roofline"]["alone"] = {"kernel_s_per_frame": r1["kernel_s_per_frame"], "achieved": r1["achieved"], "frac": r1["frac"],
                                     "frame_ms_one_lane": alone["ms_render"]}
-        out["roofline"]["lanes"] = int(os.environ.get("RTGO_LANES", "2"))
+        out["roofline"]["lanes"] = int(os.environ.get("RTGO_LANES", "4"))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, spec, args.cpu_rows)
         print(json.dumps(out), flush=True)
@@ -166,10 +176,11 @@ def roofline(shadow_s, shadow_rays, world, W, H, spp, bray):
     from the micro-benchmarks of scripts/calib.hip and scripts/calib_mix.hip run on the same box (same file).
     peak (VALU) = the rate at which the SIMDs could issue this kernel's instruction mix.  frac = busy time of the
     busiest unit / the kernel's measured time (HIP events around every k_shadow launch of the timed region).
-    A render call runs its batches on two streams (rtgo_hip.hip Lane): in the timed region a k_shadow launch shares
-    the GPU with the other lane's HBM-bound kernels (and at times with its k_shadow), so its duration includes the
-    time slices they got and `frac` is lower than the kernel's own; roofline["alone"] is the same measurement over
-    one more frame rendered on a single lane."""
+    A render call runs its batches on four streams (rtgo_hip.hip Lane), whose k_shadow launches overlap one another and
+    the other lanes' HBM-bound kernels: the kernel's time in the timed region is the time during which at least one
+    k_shadow launch was running (rt_stats.ms_shadow_busy, the union of the launches' event intervals), which still
+    includes the time slices the other kernels got, so `frac` is lower than the kernel's own; roofline["alone"] is the
+    same measurement over one more frame rendered on a single lane, where a launch has the GPU to itself."""
     out = {"bound": None, "kernel": "k_shadow", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
            "kernel_s_per_frame": shadow_s}
     # SURVEY 8d's figure, kept for the record: the REFERENCE's traversal bytes (its octree, 224 B per node) per second

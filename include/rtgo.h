@@ -146,6 +146,8 @@ typedef struct rt_stats {
                                     two streams that overlap (RTGO_LANES=1: one), the stage times are summed over
                                     them, so the three can add up to more than ms_render.                        */
     uint64_t rays_shadow_beam;   /* of rays_shadow: decided by a pair's beam walk, never generated as rays */
+    double ms_shadow_busy;       /* time during which at least one stream's k_shadow was running (the union of the
+                                    launches' intervals; = ms_shadow on one stream), if timed                     */
 } rt_stats;
 
 typedef struct rt_scene_info {

@@ -1329,7 +1329,8 @@ static int plan_render(const rt_scene* s, const rt_image_spec* spec, const rt_pa
 // numbers only size the grids (upper bounds: a queue never outgrows the one it came from).
 // Of the pixel batches (in loop order) this call takes those with index % n_lanes == lane_i.
 static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* spec, const RenderPlan& P, float* d_accum, hipStream_t stream,
-                      rt_stats* stats, bool may_create_events, int lane_i = 0, int n_lanes = 1) {
+                      rt_stats* stats, bool may_create_events, int lane_i = 0, int n_lanes = 1,
+                      hipEvent_t clock0 = nullptr, std::vector<std::pair<float, float>>* shadow_spans = nullptr) {
     const int W = spec->width, H = spec->height, D = spec->ray_tracing_max_depth, reps = spec->soft_shadow_monte_carlo_repetitions;
     const int L = s->d.n_pos_lights;
     Work& wk = arena.wk;
@@ -1435,7 +1436,12 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
             float t = 0;
             if (hipEventElapsedTime(&t, ln.ev_pool[(size_t)sp.a], ln.ev_pool[(size_t)sp.b]) != hipSuccess) continue;
             (sp.kind == 0 ? st.ms_extend : st.ms_shadow) += t;
+            if (sp.kind == 1 && clock0 && shadow_spans) {  // when this k_shadow launch ran, on the call's clock
+                float t0 = 0;
+                if (hipEventElapsedTime(&t0, clock0, ln.ev_pool[(size_t)sp.a]) == hipSuccess) shadow_spans->push_back({t0, t0 + t});
+            }
         }
+        st.ms_shadow_busy = st.ms_shadow;  // one stream: no two launches overlap
         st.ms_shade = st.ms_render - st.ms_extend - st.ms_shadow;  // everything else between the first and the last launch
         *stats = st;
     }
@@ -1471,13 +1477,14 @@ static int rt_render_accum_device_impl(rt_scene* s, const rt_image_spec* spec, c
     if (stats) HIP_TRY(hipEventRecord(s->ev_wall[0], stream));
     HIP_TRY(hipEventRecord(s->ev_fork, stream));
     std::vector<rt_stats> part_stats((size_t)n_lanes);
+    std::vector<std::vector<std::pair<float, float>>> spans((size_t)n_lanes);
     const int device = s->device;
     rc = on_every_rank(n_lanes, [&](int l) -> int {
         Lane& ln = s->lanes[l];
         HIP_TRY(hipSetDevice(device));
         hipStream_t st = l == 0 ? stream : ln.stream;
         if (l > 0) HIP_TRY(hipStreamWaitEvent(st, s->ev_fork, 0));
-        const int r = run_render(s, ln, ln.arena, spec, P, d_accum, st, stats ? &part_stats[(size_t)l] : nullptr, true, l, n_lanes);
+        const int r = run_render(s, ln, ln.arena, spec, P, d_accum, st, stats ? &part_stats[(size_t)l] : nullptr, true, l, n_lanes, s->ev_wall[0], &spans[(size_t)l]);
         if (l > 0 && r == RT_OK) HIP_TRY(hipEventRecord(ln.ev_join, st));
         return r;
     });
@@ -1501,6 +1508,17 @@ static int rt_render_accum_device_impl(rt_scene* s, const rt_image_spec* spec, c
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev_wall[0], s->ev_wall[1]));
         t.ms_render = ms;
+        // the time during which at least one lane's k_shadow was running: the union of the launches' intervals
+        std::vector<std::pair<float, float>> all;
+        for (auto& v : spans) all.insert(all.end(), v.begin(), v.end());
+        std::sort(all.begin(), all.end());
+        double busy = 0, end = -1;
+        for (const auto& iv : all) {
+            if (iv.second <= end) continue;
+            busy += iv.second - std::max<double>(iv.first, end);
+            end = iv.second;
+        }
+        t.ms_shadow_busy = busy;
         *stats = t;
     }
     return RT_OK;
@@ -1770,7 +1788,7 @@ static int rt_multi_render_impl(rt_multi* m, const rt_image_spec* spec, int32_t 
         for (const rt_stats& x : st) {
             t.rays_primary += x.rays_primary; t.rays_continuation += x.rays_continuation; t.rays_shadow += x.rays_shadow; t.rays_shadow_beam += x.rays_shadow_beam;
             t.rays_shadow_reference_equivalent += x.rays_shadow_reference_equivalent; t.phong_hits += x.phong_hits; t.paths += x.paths;
-            t.ms_build = std::max(t.ms_build, x.ms_build); t.ms_render = std::max(t.ms_render, x.ms_render);
+            t.ms_build = std::max(t.ms_build, x.ms_build); t.ms_render = std::max(t.ms_render, x.ms_render); t.ms_shadow_busy += x.ms_shadow_busy;
             t.ms_extend = std::max(t.ms_extend, x.ms_extend); t.ms_shadow = std::max(t.ms_shadow, x.ms_shadow); t.ms_shade = std::max(t.ms_shade, x.ms_shade);
         }
         *stats = t;
