@@ -143,7 +143,7 @@ typedef struct rt_stats {
     double ms_render;            /* device time of the render call (hipEvent)          */
     double ms_extend, ms_shadow, ms_shade; /* per-stage stream time, if timed: the launch durations of k_extend and of
                                     k_shadow, and the rest of each stream's span.  A render call runs its batches on
-                                    two streams that overlap (RTGO_LANES=1: one), the stage times are summed over
+                                    up to four streams that overlap (RTGO_LANES=1: one), the stage times are summed over
                                     them, so the three can add up to more than ms_render.                        */
     uint64_t rays_shadow_beam;   /* of rays_shadow: decided by a pair's beam walk, never generated as rays */
     double ms_shadow_busy;       /* time during which at least one stream's k_shadow was running (the union of the
@@ -191,9 +191,9 @@ int rt_render(rt_scene* scene, const rt_image_spec* spec, const rt_partition* pa
  * the queue lengths (on an event recorded before that bounce's shadow rays, so the stream
  * itself never drains).  With stats != NULL it returns when the frame is complete; with
  * stats == NULL it returns once the last batch is enqueued, its tail still running on the
- * stream.  Half of the batches run on a second stream that the scene owns (and a host thread
- * that lives for the call), forked from hip_stream at the start of the call and joined back
- * to it at the end: what the caller queued on hip_stream before the call is seen by every
+ * stream.  The batches are dealt out over up to four streams — hip_stream and three that the
+ * scene owns, each fed by a host thread that lives for the call — forked from hip_stream at
+ * the start of the call and joined back to it at the end: what the caller queued on hip_stream before the call is seen by every
  * batch, what it queues afterwards comes after all of them (RTGO_LANES=1: one stream). */
 int rt_render_accum_device(rt_scene* scene, const rt_image_spec* spec, const rt_partition* part,
                            float* d_accum_rgb, void* hip_stream, rt_stats* stats);
