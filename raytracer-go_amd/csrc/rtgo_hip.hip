@@ -1319,6 +1319,17 @@ static int plan_render(const rt_scene* s, const rt_image_spec* spec, const rt_pa
     if (max_paths > pair_cap) max_paths = pair_cap;
     P->ns_max = (int)std::min<long long>(P->sB - P->sA, std::min<long long>(64, max_paths / ((long long)tile * tile)));
     P->pix_per_batch = std::max<long long>(1, max_paths / P->ns_max / ((long long)tile * tile)) * tile * tile;
+    // a share of fewer batches than lanes is cut into as many batches as there are lanes, as long as a batch keeps
+    // 2^20 paths (which pixels share a batch changes no value: a pixel's samples are summed in index order)
+    if (paths_cap <= 0 && part.max_paths_per_batch <= 0) {
+        const long long tt = (long long)tile * tile;
+        const long long n_tiles = P->n_local_pixels / tt;
+        const long long n_batches = (P->n_local_pixels + P->pix_per_batch - 1) / P->pix_per_batch;
+        if (n_batches < kLanes && n_tiles >= kLanes) {
+            const long long per = ((n_tiles + kLanes - 1) / kLanes) * tt;
+            if (per * P->ns_max >= ((long long)1 << 20)) P->pix_per_batch = per;
+        }
+    }
     P->batch_paths = (int64_t)std::min<long long>(P->pix_per_batch, P->n_local_pixels) * P->ns_max;
     return RT_OK;
 }

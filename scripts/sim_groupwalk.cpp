@@ -552,3 +552,78 @@ extern "C" int sim_ball_beam(const orc_scene* s, const rt_image_spec* spec, uint
         }
     return 0;
 }
+
+// ---- would the occluder of a pair's CENTRAL ray (p -> the light's centre) decide its other rays? ---------------
+// out: [0] rays of pairs that are not clear by sim_ball_beam's criterion (approximated: pairs with an occluded ray or
+// whose central ray is occluded are surely not clear; lit pairs are left out), [1] occluded rays among them,
+// [2] occluded rays that the central ray's triangle also occludes, [3] ... that some triangle of that triangle's leaf
+// occludes, [4] pairs considered, [5] pairs whose central ray is occluded, [6] visits of the central rays
+extern "C" int sim_central(const orc_scene* s, const rt_image_spec* spec, uint64_t seed, double* out) {
+    const Scene& sc = s->sc;
+    const int W = spec->width, H = spec->height, reps = spec->soft_shadow_monte_carlo_repetitions;
+    const CameraF64 c64 = new_camera(sc, W, H);
+    const Camera<float> cf = narrow_camera<float>(c64);
+    const Tables<float>& T = sc.t32;
+    for (int i = 0; i < 7; ++i) out[i] = 0;
+    // leaf of every shape: the as_leaf node that holds it
+    std::unordered_map<int, Node*> leaf_of;
+    {
+        std::vector<Node*> todo{effective(sc.wide_root)};
+        while (!todo.empty()) {
+            Node* x = todo.back(); todo.pop_back();
+            if (x->as_leaf || x->leaf) { std::vector<int> g; subtree_shapes(x, &g); for (int q : g) leaf_of[q] = x; continue; }
+            for (Node* e : x->slot) if (e) todo.push_back(e);
+        }
+    }
+    auto occludes = [&](int shape, const Ray<float>& ray, float dist) {
+        const Hit<float> h = T.shapes[(size_t)shape].kind == RT_SHAPE_TRIANGLE ? triangle_occludes_f32(T.shapes[(size_t)shape], shape, ray, 0.01f, dist)
+                                                                                : shape_hit(T, shape, ray, 0.01f, dist);
+        return h.t > 0.0f && h.t <= dist;
+    };
+    for (int row = 0; row < H; ++row)
+        for (int i = 0; i < W; ++i) {
+            const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(row * W + i), 0u};
+            const Ray<float> r = camera_ray(cf, W, H, i, H - 1 - row, key);
+            Hit<float> hit;
+            if (!trace_stack_f32(sc, r, 0.0f, FLT_MAX, false, hit, nullptr)) continue;
+            const Material<float>& m = T.materials[T.shapes[hit.shape].material];
+            if (m.kind != RT_MAT_PHONGBLINN) continue;
+            int lpos = -1;
+            for (size_t li = 0; li < T.lights.size(); ++li) {
+                const Light<float>& L = T.lights[li];
+                if (L.kind == RT_LIGHT_AMBIENT) continue;
+                ++lpos;
+                const V3<float> ldir = unit(sub(L.pos, hit.p));
+                const float inten = saturate(dot(hit.normal, ldir));
+                const V3<float> h = unit(add(ldir, r.d));
+                const float si = std::pow(saturate(dot(hit.normal, h)), m.param);
+                if (inten == 0.0f && (si == 0.0f || (m.spec.x == 0 && m.spec.y == 0 && m.spec.z == 0))) continue;
+                // central ray
+                const V3<float> cd = sub(L.pos, hit.p);
+                const float cdist = norm(cd);
+                TraceCounters tc; Hit<float> ch;
+                const bool cocc = trace_stack_f32(sc, Ray<float>{hit.p, scale(1.0f / cdist, cd)}, 0.01f, cdist, true, ch, &tc);
+                std::vector<int> leafshapes;
+                if (cocc) { auto it = leaf_of.find(ch.shape); if (it != leaf_of.end()) subtree_shapes(it->second, &leafshapes); }
+                int n_rays = 0, n_occ = 0, by_tri = 0, by_leaf = 0;
+                for (int k = 0; k < reps; ++k) {
+                    const V3<float> jit = scale(0.25f, random_in_unit_sphere<float>(key, 0, P_SHADOW, (uint32_t)(lpos * reps + k)));
+                    const V3<float> shifted = add(L.pos, jit);
+                    if (L.kind == RT_LIGHT_SPOT && !(dot(L.look_dir, unit(sub(hit.p, shifted))) >= L.cos_angle)) continue;
+                    const V3<float> ld = sub(shifted, hit.p);
+                    const float d = norm(ld);
+                    const Ray<float> ray{hit.p, scale(1.0f / d, ld)};
+                    Hit<float> hh;
+                    const bool occ = trace_stack_f32(sc, ray, 0.01f, d, true, hh, nullptr);
+                    ++n_rays;
+                    if (!occ) continue;
+                    ++n_occ;
+                    if (cocc && occludes(ch.shape, ray, d)) { ++by_tri; ++by_leaf; continue; }
+                    for (int q : leafshapes) if (occludes(q, ray, d)) { ++by_leaf; break; }
+                }
+                if (n_occ == 0 && !cocc) continue;
+                out[0] += n_rays; out[1] += n_occ; out[2] += by_tri; out[3] += by_leaf; out[4] += 1; out[5] += cocc; out[6] += (double)tc.inner;
+            }
+        }
+    return 0;
+}
