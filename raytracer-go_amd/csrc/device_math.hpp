@@ -209,7 +209,7 @@ __device__ unsigned long long g_prof2[4];  // shadow-ray walk: iterations, lanes
 // Holding a leaf back cannot change the result: a lane's shapes are still tested in the same order,
 // and a box that a smaller `best` would have culled holds no hit below that `best`.
 #ifndef RTGO_LDS_STACK
-#define RTGO_LDS_STACK 15
+#define RTGO_LDS_STACK 11
 #endif
 constexpr int kLdsStackDepth = RTGO_LDS_STACK;
 #ifndef RTGO_PEND_CAP

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_beam(DScene S, Batch B, Work Wk
 // a power of two <= 64; each lane runs repetitions r, r+group, ...  The visible repetitions of a
 // (hit, light) are counted with a ballot popcount: integer, so the result has no summation order.
 #ifndef RTGO_SHADOW_WAVES
-#define RTGO_SHADOW_WAVES 6  // k_shadow ms per frame at config 3 (quantised walk): 5 waves (LDS stack 20) 416, 6 (15) 395, 7 (11) 392, 8 (8) 404
+#define RTGO_SHADOW_WAVES 7  // k_shadow ms per frame at config 3 (quantised walk): 5 waves (LDS stack 20) 416, 6 (15) 395, 7 (11) 392, 8 (8) 404; with pair beams (hard rays only): 6 (15) 299.4, 6 (13) 300.6, 7 (11) 293.1, 7 (10) 293.5
 #endif
 __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, Batch B, Work Wk, const uint32_t* n_hits_ptr, int bounce,
                                                    int group, int group_shift, const uint32_t* pairs, const uint32_t* pair_counter) {
@@ -792,7 +792,7 @@ struct rt_scene {
 constexpr int64_t kStaticPaths = (int64_t)1 << 18;  // (pixel, sample) paths of one batch
 constexpr int kStaticLights = 4;                    // positional lights
 constexpr int kStaticDepth = 64;                    // RayTracingMaxDepth
-constexpr int kStaticSpill = 40;                    // traversal-stack entries per lane beyond the LDS part
+constexpr int kStaticSpill = 44;                    // traversal-stack entries per lane beyond the LDS part
 constexpr int kStaticGrid = 768;                    // blocks of a grid-stride launch (the spill region is per thread of it)
 constexpr size_t kScratchBytes = (size_t)72 << 20;
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
