@@ -90,6 +90,7 @@ struct DScene {
     const float4* prims;   // 3 float4 per shape, in LEAF order: tri {A, B.x}{B.yz, C.xy}{C.z, bits, -, -}; sphere {C, R}{-}{-, bits}
     const float4* tprims;  // the same for the intersection tests: edges e1 = B - A, e2 = C - A in place of B, C
     const int* prim_ids;   // leaf-order shape q -> position in Scene.Shapes
+    const uint32_t* block_of_first;  // first child record of a block -> index of the block (qblocks)
     const DMaterial* materials;
     const DTexture* textures;
     const DLight* lights;
@@ -478,7 +479,17 @@ RT_DEV void beam_visit_block(const DScene& S, uint32_t cur, const Beam& bm, uint
     *inner_mask = hit & ~(m >> 8);
 }
 // true: no leaf box of the tree meets the beam.  Every lane of the wavefront calls it (live = this lane has a beam).
-RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, const Beam& bm) {
+// A walk that meets a leaf stops there and, if `resume` is given, leaves its state for the pair's rays: every block it
+// has been through held no leaf that the beam meets — so none that a ray of the pair could hit — and every inner child
+// the beam met is either visited already or still on its stack.  The rays therefore need not start at the root: they
+// resume at the block where the beam stopped, with the beam's stack (config 3, CPU simulation: 8.1 entries; 10.7
+// instead of 13.2 block visits per ray, the visits of inherited blocks that a ray then misses included).
+//   resume[0] = entries of the stack (kResumeRoot: start at the root instead), resume[1] = the block to enter,
+//   resume[2 ..] = the stack, bottom first; all as indices of quantised blocks.
+constexpr int kResumeWords = 16;
+constexpr int kResumeStack = kLdsStackDepth < kResumeWords - 2 ? kLdsStackDepth : kResumeWords - 2;  // entries handed over at most
+constexpr uint32_t kResumeRoot = 0xffffffffu;
+RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, const Beam& bm, uint32_t* cur_out, int* sp_out) {
     uint32_t cur = S.root_ref;
     int sp = 0;
     bool walking = live, clear = true;
@@ -491,7 +502,19 @@ RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, cons
             else walking = next_block(st, ref, inner_mask, &cur, &sp);
         }
     }
+    *cur_out = cur;  // where a walk that met a leaf stopped; its stack is st.get(0 .. sp - 1)
+    *sp_out = sp;
     return clear;
+}
+// The state of a stopped beam walk, as the pair's rays will read it
+RT_DEV void write_resume(const DScene& S, const TraceStack& st, uint32_t cur, int sp, uint32_t* resume) {
+    if (sp <= kResumeStack) {
+        resume[0] = (uint32_t)sp;
+        resume[1] = S.block_of_first[cur >> 8];
+        for (int k = 0; k < sp; ++k) resume[2 + k] = S.block_of_first[st.get(k) >> 8];
+    } else {
+        resume[0] = kResumeRoot;
+    }
 }
 
 // ---- the shadow-ray walk over quantised blocks ------------------------------------------------
@@ -681,7 +704,7 @@ RT_DEV uint32_t wave_scan_max(uint32_t x) {
 // SAME_TMIN: tmin is the same for every lane of the wavefront (k_shadow's constant), so a lane that tests
 // another lane's shape need not fetch it with the rest of that lane's ray.
 template <bool SAME_TMIN>
-RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 d, float tmin, float tmax) {
+RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 d, float tmin, float tmax, const uint32_t* resume = nullptr) {
     // Called by ALL 64 lanes of a wavefront (live = this lane has a ray).  The lanes walk their own rays, but
     // the shape loop is shared: the queued shapes of all lanes are dealt out evenly, one shape per lane and
     // round, whoever's ray it belongs to.  (Lane utilisation of the shape tests 0.91, against 0.38 when every
@@ -690,6 +713,18 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
     uint32_t cur = 0u;  // block index; the root is block 0
     int sp = 0;
     bool walking = live;
+    if (live && resume) {  // the state a beam walk left for this ray's pair (beam_is_clear): at most kResumeStack entries,
+        // all fetched at once and stored to the LDS part of the stack without a branch per entry
+        const uint4* q = reinterpret_cast<const uint4*>(resume);
+        const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
+        const uint32_t e[kResumeWords] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+        if (e[0] != kResumeRoot) {
+            cur = e[1];
+            sp = (int)e[0];
+#pragma unroll
+            for (int k = 0; k < kResumeStack; ++k) st.lds[k * st.lds_stride] = e[2 + k];  // entries past sp are never read
+        }
+    }
     bool occ = false;
     uint32_t npend = 0;
     uint32_t* const pend = st.lds + kLdsStackDepth * st.lds_stride;

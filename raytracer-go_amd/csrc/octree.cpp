@@ -650,6 +650,7 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
     out->records.clear();
     out->qblocks.clear();
     out->order.clear();
+    out->block_of_first.assign(1, 0u);
     out->root_ref = 0; out->n_inner = 0; out->depth = 0; out->stack_bound = 1;
     if (nodes.empty() || nodes[0].empty) {  // no shapes: present mask 0 => every ray misses
         out->qblocks.assign(kQBlockWords, 0u);
@@ -685,6 +686,7 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
         out->root_ref = (0u << 8) | 1u;
         out->n_inner = 1; out->depth = 1; out->stack_bound = 8;
         append_qblock(out, 0, 1, 1u, 1u, 0u);
+        out->block_of_first.assign(2, 0u);
         return true;
     }
     queue.push_back({root, -1, 1});
@@ -728,6 +730,8 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
         out->n_inner++;
         if (p.level > out->depth) out->depth = p.level;
     }
+    out->block_of_first.assign(out->records.size() + 1, 0u);
+    for (size_t i = 0; i < blocks.size(); ++i) out->block_of_first[(size_t)blocks[i].first] = (uint32_t)i;
     // Worst-case traversal stack: entering a block pushes at most (inner children - 1) entries and descends
     // into one inner child, so the deepest stack below block b is need(b) = (inner(b) - 1) + max over its
     // inner children of need(child).  Blocks are in breadth-first order: children come after their parent.

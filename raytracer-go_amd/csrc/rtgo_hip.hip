@@ -100,6 +100,7 @@ struct Work {
     unsigned long long* frame_counters;  // per call: [0] shadow rays traced, [1] shadow rays decided by a pair's beam walk
     uint32_t* overflow;  // traversal stack spill
     uint32_t overflow_stride;
+    uint32_t* beam_state;  // per pair of the queue k_pair_beam builds: kResumeWords words its rays resume from (nullptr: none kept)
 };
 
 // Queue compaction: ballot + popcount prefix inside a wavefront, the wavefronts' counts combined through
@@ -424,14 +425,22 @@ __global__ __launch_bounds__(kBlock) void k_pair_beam(DScene S, Batch B, Work Wk
             judge = surely_inside_cone(L, p);
             if (judge) bm = make_beam(p, ld3(L.pos), 0.25f * 1.0001f + 1e-5f, 0.01f);
         }
-        const bool clear = beam_is_clear(S, st, judge, bm) && judge;
+        uint32_t stop_block = 0;
+        int stop_sp = 0;
+        const bool clear = beam_is_clear(S, st, judge, bm, &stop_block, &stop_sp) && judge;
         if (clear) {
             Wk.vis[(size_t)hit_i * S.n_pos_lights + lp] = (uint32_t)B.reps;
             decided += (unsigned long long)B.reps;
         }
         const bool keep = live && !clear;
         const uint32_t at = block_push(out_counter, keep);
-        if (keep) Wk.pair_seg[at] = hl;
+        if (keep) {
+            Wk.pair_seg[at] = hl;
+            if (Wk.beam_state) {  // the walk's stack is still in place (LDS + spill region) until the next round
+                uint32_t* dst = Wk.beam_state + (size_t)at * kResumeWords;
+                if (judge) write_resume(S, st, stop_block, stop_sp, dst); else dst[0] = kResumeRoot;
+            }
+        }
     }
     for (int off = 32; off > 0; off >>= 1) decided += __shfl_down(decided, off);
     if (__lane_id() == 0 && decided) atomicAdd(Wk.frame_counters + 1, decided);
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_beam(DScene S, Batch B, Work Wk
 #define RTGO_SHADOW_WAVES 7  // k_shadow ms per frame at config 3 (quantised walk): 5 waves (LDS stack 20) 416, 6 (15) 395, 7 (11) 392, 8 (8) 404; with pair beams (hard rays only): 6 (15) 299.4, 6 (13) 300.6, 7 (11) 293.1, 7 (10) 293.5
 #endif
 __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, Batch B, Work Wk, const uint32_t* n_hits_ptr, int bounce,
-                                                   int group, int group_shift, const uint32_t* pairs, const uint32_t* pair_counter) {
+                                                   int group, int group_shift, const uint32_t* pairs, const uint32_t* pair_counter, const uint32_t* beam_state) {
     __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
     const uint32_t n_hits = *n_hits_ptr;
     __shared__ uint32_t s_wave[(kBlock / 64) * 128];
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
             }
             RT_PROF_POINT(2);  // shadow-ray rounds
             // all 64 lanes call: lanes without a ray of their own test shapes for the others
-            const bool occ = occluded<true>(S, st, traced, p, dir, 0.01f, dist);
+            const bool occ = occluded<true>(S, st, traced, p, dir, 0.01f, dist, beam_state ? beam_state + (size_t)(idx >> group_shift) * kResumeWords : nullptr);
             vis = traced && !occ;
             const unsigned long long m = __ballot(vis);
             count += (uint32_t)__popcll(m & gmask);
@@ -772,7 +781,7 @@ constexpr int kLanes = 4;
 struct rt_scene {
     int device = 0;
     DScene d{};
-    void* d_recs = nullptr; void* d_qblocks = nullptr; void* d_prims = nullptr; void* d_tprims = nullptr; void* d_prim_ids = nullptr; void* d_mats = nullptr; void* d_texs = nullptr; void* d_lights = nullptr;
+    void* d_recs = nullptr; void* d_qblocks = nullptr; void* d_prims = nullptr; void* d_tprims = nullptr; void* d_prim_ids = nullptr; void* d_block_of_first = nullptr; void* d_mats = nullptr; void* d_texs = nullptr; void* d_lights = nullptr;
     std::vector<void*> d_tex_pixels;
     rt_scene_info info{};
     double ms_build = 0;
@@ -807,7 +816,8 @@ constexpr size_t kAlign = 256;
 inline size_t align_up(size_t n) { return (n + kAlign - 1) / kAlign * kAlign; }
 
 // Lays the arrays of a batch workspace out over `base` (nullptr: only measure).  Returns the bytes needed.
-size_t carve_work(Work* w, unsigned char* base, int64_t paths, int depth, int lpos, unsigned long long overflow_entries) {
+size_t carve_work(Work* w, unsigned char* base, int64_t paths, int depth, int lpos, unsigned long long overflow_entries,
+                  unsigned long long resume_pairs = 0) {
     size_t off = 0;
     auto take = [&](size_t n) { unsigned char* p = base ? base + off : nullptr; off += align_up(n); return p; };
     const size_t P = (size_t)paths, L = (size_t)(lpos > 0 ? lpos : 1);
@@ -826,6 +836,7 @@ size_t carve_work(Work* w, unsigned char* base, int64_t paths, int depth, int lp
     w->counters = (uint32_t*)take((size_t)(3 * depth + 8) * sizeof(uint32_t));
     w->frame_counters = (unsigned long long*)take(4 * sizeof(unsigned long long));
     w->overflow = (uint32_t*)take((size_t)overflow_entries * sizeof(uint32_t));
+    w->beam_state = resume_pairs ? (uint32_t*)take((size_t)resume_pairs * kResumeWords * sizeof(uint32_t)) : nullptr;
     return off;
 }
 
@@ -850,11 +861,12 @@ int ensure_work(rt_scene* s, Lane& ln, int64_t paths, int depth, int lpos, unsig
     const int nd = std::max(depth, a.depth), nl = std::max(lpos, a.lpos);
     const unsigned long long ne = std::max(entries, a.overflow_entries);
     Work w{};
-    const size_t need = carve_work(&w, nullptr, np, nd, nl, ne);
+    const unsigned long long n_resume = (unsigned long long)np * (unsigned long long)std::max(1, nl);  // one state per (path, light)
+    const size_t need = carve_work(&w, nullptr, np, nd, nl, ne, n_resume);
     if (a.base) { (void)hipFree(a.base); a.base = nullptr; a.bytes = 0; a.paths = 0; a.depth = 0; a.lpos = 0; a.overflow_entries = 0; }
     HIP_TRY(hipMalloc((void**)&a.base, need));
     a.bytes = need;
-    (void)carve_work(&a.wk, a.base, np, nd, nl, ne);
+    (void)carve_work(&a.wk, a.base, np, nd, nl, ne, n_resume);
     a.paths = np; a.depth = nd; a.lpos = nl; a.overflow_entries = ne;
     a.wk.overflow_stride = s->spill > 0 ? (uint32_t)(ne / (unsigned long long)(s->spill + 1)) : 0u;
     const size_t words = (size_t)(3 * nd + 8);
@@ -1181,6 +1193,8 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     HIP_TRY_S(hipMemcpy(s->d_tprims, tprims.data(), tprims.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_prim_ids, (flat.order.size() + 1) * sizeof(int32_t)));
     if (!flat.order.empty()) HIP_TRY_S(hipMemcpy(s->d_prim_ids, flat.order.data(), flat.order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_block_of_first, flat.block_of_first.size() * sizeof(uint32_t)));
+    HIP_TRY_S(hipMemcpy(s->d_block_of_first, flat.block_of_first.data(), flat.block_of_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_mats, mats.size() * sizeof(DMaterial)));
     HIP_TRY_S(hipMemcpy(s->d_mats, mats.data(), mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_texs, texs.size() * sizeof(DTexture)));
@@ -1193,7 +1207,7 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     const int spill = flat.stack_bound + 1 > kLdsStackDepth ? flat.stack_bound + 1 - kLdsStackDepth : 0;  // +1: the nearest child is pushed, then popped
     s->spill = spill;  // the region itself is sized by ensure_overflow() for the grids a call really launches
 
-    s->d.recs = (const float4*)s->d_recs; s->d.qblocks = (const uint4*)s->d_qblocks; s->d.prims = (const float4*)s->d_prims; s->d.tprims = (const float4*)s->d_tprims; s->d.prim_ids = (const int*)s->d_prim_ids;
+    s->d.recs = (const float4*)s->d_recs; s->d.qblocks = (const uint4*)s->d_qblocks; s->d.prims = (const float4*)s->d_prims; s->d.tprims = (const float4*)s->d_tprims; s->d.prim_ids = (const int*)s->d_prim_ids; s->d.block_of_first = (const uint32_t*)s->d_block_of_first;
     s->d.materials = (const DMaterial*)s->d_mats; s->d.textures = (const DTexture*)s->d_texs;
     s->d.lights = (const DLight*)s->d_lights;
     s->d.n_lights = (int)desc->n_lights; s->d.n_pos_lights = n_pos; s->d.root_ref = flat.root_ref;
@@ -1240,7 +1254,7 @@ void rt_scene_destroy(rt_scene* s) {
     }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     for (auto& e : s->ev_wall) if (e) (void)hipEventDestroy(e);
-    void* ptrs[] = {s->d_recs, s->d_qblocks, s->d_prims, s->d_tprims, s->d_prim_ids, s->d_mats, s->d_texs, s->d_lights};
+    void* ptrs[] = {s->d_recs, s->d_qblocks, s->d_prims, s->d_tprims, s->d_prim_ids, s->d_block_of_first, s->d_mats, s->d_texs, s->d_lights};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : s->d_tex_pixels) (void)hipFree(p);
     for (DevBuf* b : {&s->accum, &s->rgba, &s->probe_in, &s->probe_out, &s->probe_out2}) b->release();
@@ -1352,6 +1366,8 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
     const bool timed = stats != nullptr;
     const char* beam_env = std::getenv("RTGO_BEAM");  // "0": every pair's rays are traced one by one (A/B switch)
     const bool beams = !(beam_env && beam_env[0] == '0');
+    const char* resume_env = std::getenv("RTGO_RESUME");  // "0": rays start at the root, not where their pair's beam stopped (A/B switch)
+    const bool resume_on = !(resume_env && resume_env[0] == '0');
     const bool staged = timed && may_create_events;  // per-stage events (and their host-side list) only where the entry point may allocate
     size_t ev_used = 0;
     auto stamp = [&]() -> int {  // one timing event on the stream, from the pool (grown only where the entry point may allocate)
@@ -1407,14 +1423,16 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
                     if (reps > 0) {
                         const uint32_t* queue = wk.pairs;
                         const uint32_t* queue_len = pair_counter;
+                        const uint32_t* resume = nullptr;
                         if (beams) {  // pairs whose rays one conservative walk proves unoccluded never reach k_shadow
                             hipLaunchKernelGGL(k_pair_beam, dim3(grid_for(n_pairs, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, B, wk, n_phong, pair_counter);
                             queue = wk.pair_seg;
                             queue_len = wk.light_count + 2 * L;
+                            resume = resume_on ? wk.beam_state : nullptr;
                         }
                         if (staged) ss.a = stamp();  // ms_shadow brackets k_shadow alone
                         hipLaunchKernelGGL(k_shadow, dim3(grid_for(n_pairs * P.group, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, B, wk, n_phong, b,
-                                           P.group, P.group_shift, queue, queue_len);
+                                           P.group, P.group_shift, queue, queue_len, resume);
                         if (staged) ss.b = stamp();
                     }
                 }

@@ -464,7 +464,7 @@ extern "C" int sim_ball_beam(const orc_scene* s, const rt_image_spec* spec, uint
     const Camera<float> cf = narrow_camera<float>(c64);
     const Tables<float>& T = sc.t32;
     Node* root = effective(sc.wide_root);
-    for (int i = 0; i < 13; ++i) out[i] = 0;
+    for (int i = 0; i < 17; ++i) out[i] = 0;
     for (int row = 0; row < H; ++row)
         for (int i = 0; i < W; ++i) {
             const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(row * W + i), 0u};
@@ -485,6 +485,7 @@ extern "C" int sim_ball_beam(const orc_scene* s, const rt_image_spec* spec, uint
                 const float si = std::pow(saturate(dot(hit.normal, h)), m.param);
                 if (inten == 0.0f && (si == 0.0f || (m.spec.x == 0 && m.spec.y == 0 && m.spec.z == 0))) continue;
                 int n_rays = 0, n_occ = 0; double ray_visits = 0;
+                std::vector<Ray<float>> prays; std::vector<float> pdist; std::vector<char> pocc;
                 for (int k = 0; k < reps; ++k) {
                     const V3<float> jit = scale(0.25f, random_in_unit_sphere<float>(key, 0, P_SHADOW, (uint32_t)(lpos * reps + k)));
                     const V3<float> shifted = add(L.pos, jit);
@@ -492,7 +493,9 @@ extern "C" int sim_ball_beam(const orc_scene* s, const rt_image_spec* spec, uint
                     const V3<float> ld = sub(shifted, hit.p);
                     const float d = norm(ld);
                     TraceCounters tc; Hit<float> hh;
-                    n_occ += trace_stack_f32(sc, Ray<float>{hit.p, scale(1.0f / d, ld)}, 0.01f, d, true, hh, &tc) ? 1 : 0;
+                    const bool oc = trace_stack_f32(sc, Ray<float>{hit.p, scale(1.0f / d, ld)}, 0.01f, d, true, hh, &tc);
+                    n_occ += oc ? 1 : 0;
+                    prays.push_back(Ray<float>{hit.p, scale(1.0f / d, ld)}); pdist.push_back(d); pocc.push_back(oc);
                     ray_visits += (double)tc.inner;
                     ++n_rays;
                 }
@@ -547,7 +550,23 @@ extern "C" int sim_ball_beam(const orc_scene* s, const rt_image_spec* spec, uint
                 }
                 out[0] += 1; out[3] += n_rays; out[7] += ray_visits;
                 if (clear) { out[1] += 1; out[2] += n_rays; out[4] += visits; out[6] += ray_visits; if (n_occ) out[8] += 1; }
-                else { out[5] += visits; out[9] += prefix; out[10] += ray_visits; out[11] += n_rays; }
+                else {
+                    out[5] += visits; out[9] += prefix; out[10] += ray_visits; out[11] += n_rays;
+                    // hand-over: the rays resume from the beam's state (the block where it met a leaf + its stack)
+                    out[13] += (double)stack.size();
+                    for (size_t k = 0; k < prays.size(); ++k) {
+                        bool found = false; double v = 0, sh = 0;
+                        std::vector<Node*> starts{cur};
+                        for (size_t q = stack.size(); q-- > 0;) starts.push_back(stack[q]);
+                        for (Node* st0 : starts) {
+                            const WalkResult w = walk_from(sc, st0, prays[k], 0.01f, pdist[k]);
+                            v += w.inner; sh += w.shapes;
+                            if (w.hit) { found = true; break; }
+                        }
+                        if (found != (bool)pocc[k]) out[16] += 1;
+                        out[14] += v; out[15] += sh;
+                    }
+                }
             }
         }
     return 0;
