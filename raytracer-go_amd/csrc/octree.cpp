@@ -651,9 +651,11 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
     out->qblocks.clear();
     out->order.clear();
     out->block_of_first.assign(1, 0u);
+    out->block_box.clear();
     out->root_ref = 0; out->n_inner = 0; out->depth = 0; out->stack_bound = 1;
     if (nodes.empty() || nodes[0].empty) {  // no shapes: present mask 0 => every ray misses
         out->qblocks.assign(kQBlockWords, 0u);
+        out->block_box.assign(8, 0.0f);
         return true;
     }
     if (leaf_size < 1) leaf_size = 1;
@@ -687,6 +689,8 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
         out->n_inner = 1; out->depth = 1; out->stack_bound = 8;
         append_qblock(out, 0, 1, 1u, 1u, 0u);
         out->block_of_first.assign(2, 0u);
+        out->block_box.assign(8, 0.0f);
+        for (int a = 0; a < 3; ++a) { out->block_box[(size_t)a] = r.bmin[a]; out->block_box[(size_t)(4 + a)] = r.bmax[a]; }
         return true;
     }
     queue.push_back({root, -1, 1});
@@ -731,7 +735,16 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
         if (p.level > out->depth) out->depth = p.level;
     }
     out->block_of_first.assign(out->records.size() + 1, 0u);
-    for (size_t i = 0; i < blocks.size(); ++i) out->block_of_first[(size_t)blocks[i].first] = (uint32_t)i;
+    out->block_box.assign(blocks.size() * 8, 0.0f);
+    for (size_t i = 0; i < blocks.size(); ++i) {
+        out->block_of_first[(size_t)blocks[i].first] = (uint32_t)i;
+        float* bb = out->block_box.data() + i * 8;
+        const ChildRecord* rec = out->records.data() + blocks[i].first;
+        for (int a = 0; a < 3; ++a) {
+            bb[a] = rec[0].bmin[a]; bb[4 + a] = rec[0].bmax[a];
+            for (int k = 1; k < blocks[i].count; ++k) { bb[a] = std::min(bb[a], rec[k].bmin[a]); bb[4 + a] = std::max(bb[4 + a], rec[k].bmax[a]); }
+        }
+    }
     // Worst-case traversal stack: entering a block pushes at most (inner children - 1) entries and descends
     // into one inner child, so the deepest stack below block b is need(b) = (inner(b) - 1) + max over its
     // inner children of need(child).  Blocks are in breadth-first order: children come after their parent.

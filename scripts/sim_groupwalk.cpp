@@ -464,7 +464,7 @@ extern "C" int sim_ball_beam(const orc_scene* s, const rt_image_spec* spec, uint
     const Camera<float> cf = narrow_camera<float>(c64);
     const Tables<float>& T = sc.t32;
     Node* root = effective(sc.wide_root);
-    for (int i = 0; i < 17; ++i) out[i] = 0;
+    for (int i = 0; i < 18; ++i) out[i] = 0;
     for (int row = 0; row < H; ++row)
         for (int i = 0; i < W; ++i) {
             const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(row * W + i), 0u};
@@ -558,7 +558,9 @@ extern "C" int sim_ball_beam(const orc_scene* s, const rt_image_spec* spec, uint
                         bool found = false; double v = 0, sh = 0;
                         std::vector<Node*> starts{cur};
                         for (size_t q = stack.size(); q-- > 0;) starts.push_back(stack[q]);
+                        const StackRay srk = make_stack_ray(prays[k]);
                         for (Node* st0 : starts) {
+                            if (st0 != cur && !slab_f32(srk, st0->fmin, st0->fmax, 0.01f, pdist[k])) out[17] += 1;  // an inherited block the ray misses
                             const WalkResult w = walk_from(sc, st0, prays[k], 0.01f, pdist[k]);
                             v += w.inner; sh += w.shapes;
                             if (w.hit) { found = true; break; }
