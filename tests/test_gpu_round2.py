@@ -223,6 +223,7 @@ def test_pair_beams_decide_the_same_rays(backend, rt, scenes, c1, gold_dir, monk
     cases.append(("config 2, one repetition", spec2, scene2, 0.05))
     for name, spec, scene, least in cases:
         with backend.DeviceScene(scene) as dev:
+            monkeypatch.setenv("RTGO_BEAM", "1")  # forced: by default scenes of fewer than 256 shapes go without
             got, st = dev.render_accum(spec)
             monkeypatch.setenv("RTGO_BEAM", "0")
             want, st0 = dev.render_accum(spec)
@@ -233,3 +234,55 @@ def test_pair_beams_decide_the_same_rays(backend, rt, scenes, c1, gold_dir, monk
         for k in ("paths", "rays_primary", "rays_continuation", "rays_shadow", "phong_hits", "rays_shadow_reference_equivalent"):
             assert getattr(st, k) == getattr(st0, k), (name, k)
         assert st.rays_shadow_beam >= least * st.rays_shadow, name
+
+
+def test_pair_beams_on_random_scenes(backend, rt, monkeypatch):
+    """Beams and the resumed walks against plain per-ray tracing (RTGO_BEAM=0) on seeded random scenes: triangle
+    soup + spheres around the origin or 1000 units away from it, point and spot lights in the open, among the shapes
+    and right above a surface, 1 / 5 / 16 repetitions, a mirror so that later bounces shade too.  The accumulation
+    buffers and the counters must be identical."""
+    api = rt
+    total_beam = 0
+    for seed in range(6):
+        rng = np.random.default_rng(100 + seed)
+        off = np.array([0.0, 0.0, 0.0]) if seed % 2 == 0 else np.array([1000.0, -500.0, 250.0])
+        n_tri = 400 + 300 * seed
+        c = rng.uniform(-3, 3, (n_tri, 1, 3)) * np.array([1.0, 0.5, 1.0]) + np.array([0.0, 2.0, 0.0])
+        tri = c + rng.normal(0, 0.08 + 0.05 * seed, (n_tri, 3, 3)) + off
+        mat = api.PhongBlinn(ColorFrac=api.Vec(0.8, 0.7, 0.6), SpecularColorFrac=api.Vec(1, 1, 1), SpecHardness=16)
+        floor = api.PhongBlinn(ColorFrac=api.Vec(0.6, 0.6, 0.6), SpecularColorFrac=api.Vec(0.3, 0.3, 0.3), SpecHardness=4)
+        R = 12.0
+        o = off
+        V = lambda x, y, z: api.Vec(float(x + o[0]), float(y + o[1]), float(z + o[2]))
+        shapes = [api.TrianglePlane(V(-R, 0, -R), V(-R, 0, R), V(R, 0, -R), False, floor),
+                  api.TrianglePlane(V(R, 0, R), V(R, 0, -R), V(-R, 0, R), False, floor),
+                  api.TrianglePlane(V(-R, 0, R), V(-R, 8, R), V(R, 0, R), True, api.Metal(api.Vec(0.9, 0.9, 0.9), 0.0)),
+                  api.TriangleMesh(tri, False, mat)]
+        for k in range(8):
+            p = rng.uniform(-3, 3, 3)
+            shapes.append(api.Sphere(V(p[0], abs(p[1]) + 0.5, p[2]), float(rng.uniform(0.2, 0.7)), mat))
+        lights = [api.AmbientLight(api.Vec(1, 1, 1), 0.05),
+                  api.PointLight(ColorFrac=api.Vec(1, 1, 1), Position=V(4, 7, -5), LightIntensity=60, SpecularLightIntensity=20,
+                                 InverseSquareLawDecayFactor=0.5),
+                  api.PointLight(ColorFrac=api.Vec(1, 0.8, 0.8), Position=V(0.3, 2.0, 0.2), LightIntensity=10, SpecularLightIntensity=5,
+                                 InverseSquareLawDecayFactor=0.5),  # among the triangles
+                  api.SpotLight(ColorFrac=api.Vec(0.8, 0.9, 1), Position=V(-5, 0.3, -4), LightIntensity=40, SpecularLightIntensity=10,
+                                LookAt=V(0, 1, 0), Angle=35.0, InverseSquareLawDecayFactor=0.3)]  # 0.3 above the floor
+        reps = (1, 5, 16)[seed % 3]
+        spec = api.ImageSpec(160, 100, 3, 6, reps, 16, api.Dijkstra)
+        scene = api.Scene(V(0, 3.5, -9), V(0, 1.5, 0), api.Vec(0, 1, 0), V(0, 1.5, 0), 0.02, 50.0, shapes, lights)
+        with backend.DeviceScene(scene) as dev:
+            monkeypatch.setenv("RTGO_BEAM", "1")
+            got, st = dev.render_accum(spec)
+            monkeypatch.setenv("RTGO_RESUME", "0")
+            mid, st_mid = dev.render_accum(spec)
+            monkeypatch.delenv("RTGO_RESUME")
+            monkeypatch.setenv("RTGO_BEAM", "0")
+            want, st0 = dev.render_accum(spec)
+            monkeypatch.delenv("RTGO_BEAM")
+        assert np.array_equal(got, want) and np.array_equal(mid, want), (seed, np.abs(got - want).max(), np.abs(mid - want).max())
+        for k in ("paths", "rays_primary", "rays_continuation", "rays_shadow", "phong_hits"):
+            assert getattr(st, k) == getattr(st0, k) == getattr(st_mid, k), (seed, k)
+        assert st.rays_continuation > 0 and st0.rays_shadow_beam == 0
+        total_beam += st.rays_shadow_beam
+    assert total_beam > 0
