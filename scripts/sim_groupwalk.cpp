@@ -648,3 +648,119 @@ extern "C" int sim_central(const orc_scene* s, const rt_image_spec* spec, uint64
         }
     return 0;
 }
+
+// ---- the beam walk continued past the first K leaves it meets ------------------------------------------------
+// Design question: k_pair_beam stops at the first leaf box the beam meets and the pair's rays resume there.  If it
+// went on, collecting the first K leaves met, the rays would test those leaves (own box test, then shapes) and resume
+// later in the walk — or not walk at all when the beam's walk ends with at most K leaves.
+// out: [0] non-clear pairs, [1] their rays, [2] beam visits, [3] pairs whose walk ended (no ray walk at all),
+//      [4] ray block visits (resumed, inherited blocks filtered by their boxes), [5] ray leaf-box tests of collected leaves,
+//      [6] ray shape tests, [7] mismatches against the per-ray walk (must be 0), [8] handed-over stack entries
+extern "C" int sim_beam_k(const orc_scene* s, const rt_image_spec* spec, uint64_t seed, double R, int K, double* out) {
+    const Scene& sc = s->sc;
+    const int W = spec->width, H = spec->height, reps = spec->soft_shadow_monte_carlo_repetitions;
+    const CameraF64 c64 = new_camera(sc, W, H);
+    const Camera<float> cf = narrow_camera<float>(c64);
+    const Tables<float>& T = sc.t32;
+    Node* root = effective(sc.wide_root);
+    for (int i = 0; i < 9; ++i) out[i] = 0;
+    if (root->as_leaf) return 0;
+    for (int row = 0; row < H; ++row)
+        for (int i = 0; i < W; ++i) {
+            const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(row * W + i), 0u};
+            const Ray<float> r = camera_ray(cf, W, H, i, H - 1 - row, key);
+            Hit<float> hit;
+            if (!trace_stack_f32(sc, r, 0.0f, FLT_MAX, false, hit, nullptr)) continue;
+            const Material<float>& m = T.materials[T.shapes[hit.shape].material];
+            if (m.kind != RT_MAT_PHONGBLINN) continue;
+            int lpos = -1;
+            for (size_t li = 0; li < T.lights.size(); ++li) {
+                const Light<float>& L = T.lights[li];
+                if (L.kind == RT_LIGHT_AMBIENT) continue;
+                ++lpos;
+                const V3<float> ldir = unit(sub(L.pos, hit.p));
+                const float inten = saturate(dot(hit.normal, ldir));
+                const V3<float> h = unit(add(ldir, r.d));
+                const float si = std::pow(saturate(dot(hit.normal, h)), m.param);
+                if (inten == 0.0f && (si == 0.0f || (m.spec.x == 0 && m.spec.y == 0 && m.spec.z == 0))) continue;
+                std::vector<Ray<float>> prays; std::vector<float> pdist; std::vector<char> pocc;
+                for (int k = 0; k < reps; ++k) {
+                    const V3<float> jit = scale(0.25f, random_in_unit_sphere<float>(key, 0, P_SHADOW, (uint32_t)(lpos * reps + k)));
+                    const V3<float> shifted = add(L.pos, jit);
+                    if (L.kind == RT_LIGHT_SPOT && !(dot(L.look_dir, unit(sub(hit.p, shifted))) >= L.cos_angle)) continue;
+                    const V3<float> ld = sub(shifted, hit.p);
+                    const float d = norm(ld);
+                    Hit<float> hh;
+                    pocc.push_back(trace_stack_f32(sc, Ray<float>{hit.p, scale(1.0f / d, ld)}, 0.01f, d, true, hh, nullptr));
+                    prays.push_back(Ray<float>{hit.p, scale(1.0f / d, ld)}); pdist.push_back(d);
+                }
+                if (prays.empty()) continue;
+                const double p[3] = {hit.p.x, hit.p.y, hit.p.z};
+                const double D[3] = {L.pos.x - p[0], L.pos.y - p[1], L.pos.z - p[2]};
+                const double len = std::sqrt(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);
+                const double s0 = 0.01 / (len + R * 1.7320508) * 0.999, s1 = 1.0001;
+                const int sign = (D[0] < 0 ? 1 : 0) | (D[1] < 0 ? 2 : 0) | (D[2] < 0 ? 4 : 0);
+                auto meets = [&](const float* lo, const float* hi) {
+                    double a = s0, b = s1;
+                    for (int ax = 0; ax < 3; ++ax) {
+                        const double c1 = D[ax] - R, c2 = D[ax] + R;
+                        const double h1 = (double)hi[ax] - p[ax], l1 = (double)lo[ax] - p[ax];
+                        if (c1 > 0) b = std::min(b, h1 / c1); else if (c1 < 0) a = std::max(a, h1 / c1); else if (h1 < 0) return false;
+                        if (c2 > 0) a = std::max(a, l1 / c2); else if (c2 < 0) b = std::min(b, l1 / c2); else if (l1 > 0) return false;
+                    }
+                    return a <= b;
+                };
+                double visits = 0;
+                std::vector<Node*> stack, leaves;
+                Node* cur = root;
+                bool ended = false;
+                for (;;) {
+                    visits += 1;
+                    Node* pending[8]; int np = 0;
+                    std::vector<Node*> here;
+                    for (int k = 0; k < 8; ++k) {
+                        Node* e = cur->slot[k ^ sign];
+                        if (!e || !meets(e->fmin, e->fmax)) continue;
+                        if (e->as_leaf) here.push_back(e); else pending[np++] = e;
+                    }
+                    if ((int)(leaves.size() + here.size()) > K) break;  // hand over with `cur` to be visited again by the rays
+                    leaves.insert(leaves.end(), here.begin(), here.end());
+                    for (int q = np - 1; q >= 1; --q) stack.push_back(pending[q]);
+                    if (np > 0) { cur = pending[0]; continue; }
+                    if (stack.empty()) { ended = true; break; }
+                    cur = stack.back(); stack.pop_back();
+                }
+                if (ended && leaves.empty()) continue;  // a clear pair
+                out[0] += 1; out[1] += (double)prays.size(); out[2] += visits; out[3] += ended ? 1 : 0; out[8] += ended ? 0 : (double)stack.size();
+                std::vector<int> group;
+                for (size_t k = 0; k < prays.size(); ++k) {
+                    const StackRay srk = make_stack_ray(prays[k]);
+                    bool found = false;
+                    for (Node* lf : leaves) {
+                        out[5] += 1;
+                        if (!slab_f32(srk, lf->fmin, lf->fmax, 0.01f, pdist[k])) continue;
+                        group.clear(); subtree_shapes(lf, &group);
+                        for (int shape : group) {
+                            out[6] += 1;
+                            const Hit<float> shh = T.shapes[(size_t)shape].kind == RT_SHAPE_TRIANGLE ? triangle_occludes_f32(T.shapes[(size_t)shape], shape, prays[k], 0.01f, pdist[k])
+                                                                                                     : shape_hit(T, shape, prays[k], 0.01f, pdist[k]);
+                            if (shh.t > 0.0f && shh.t <= pdist[k]) { found = true; break; }
+                        }
+                        if (found) break;
+                    }
+                    if (!found && !ended) {
+                        std::vector<Node*> starts{cur};
+                        for (size_t q = stack.size(); q-- > 0;) starts.push_back(stack[q]);
+                        for (Node* st0 : starts) {
+                            if (st0 != cur && !slab_f32(srk, st0->fmin, st0->fmax, 0.01f, pdist[k])) continue;  // filtered at set-up
+                            const WalkResult w = walk_from(sc, st0, prays[k], 0.01f, pdist[k]);
+                            out[4] += w.inner; out[6] += w.shapes;
+                            if (w.hit) { found = true; break; }
+                        }
+                    }
+                    if (found != (bool)pocc[k]) out[7] += 1;
+                }
+            }
+        }
+    return 0;
+}
