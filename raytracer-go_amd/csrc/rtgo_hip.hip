@@ -861,7 +861,8 @@ int ensure_work(rt_scene* s, Lane& ln, int64_t paths, int depth, int lpos, unsig
     const int nd = std::max(depth, a.depth), nl = std::max(lpos, a.lpos);
     const unsigned long long ne = std::max(entries, a.overflow_entries);
     Work w{};
-    const unsigned long long n_resume = (unsigned long long)np * (unsigned long long)std::max(1, nl);  // one state per (path, light)
+    unsigned long long n_resume = (unsigned long long)np * (unsigned long long)std::max(1, nl);  // one state per (path, light)
+    if (n_resume * kResumeWords * sizeof(uint32_t) > ((size_t)4 << 30)) n_resume = 0;  // many lights: the rays then start at the root
     const size_t need = carve_work(&w, nullptr, np, nd, nl, ne, n_resume);
     if (a.base) { (void)hipFree(a.base); a.base = nullptr; a.bytes = 0; a.paths = 0; a.depth = 0; a.lpos = 0; a.overflow_entries = 0; }
     HIP_TRY(hipMalloc((void**)&a.base, need));
