@@ -90,7 +90,7 @@ struct DScene {
     const float4* prims;   // 3 float4 per shape, in LEAF order: tri {A, B.x}{B.yz, C.xy}{C.z, bits, -, -}; sphere {C, R}{-}{-, bits}
     const float4* tprims;  // the same for the intersection tests: edges e1 = B - A, e2 = C - A in place of B, C
     const int* prim_ids;   // leaf-order shape q -> position in Scene.Shapes
-    const uint32_t* block_of_first;  // first child record of a block -> index of the block (qblocks)
+    const uint32_t* block_first;     // per block (qblocks): its first child record (recs)
     const float4* block_box;         // 2 float4 per block: {min.xyz, -}, {max.xyz, -} of its children's boxes
     const DMaterial* materials;
     const DTexture* textures;
@@ -440,84 +440,6 @@ RT_DEV Beam make_beam(f3 p, f3 light, float R, float tmin) {
     b.s1 = 1.0001f;
     return b;
 }
-// visit_block() for a beam: bit k of the masks = position k of the order slot = k ^ sign
-RT_DEV void beam_visit_block(const DScene& S, uint32_t cur, const Beam& bm, uint32_t ref[8], uint32_t* leaf_mask, uint32_t* inner_mask) {
-    const uint32_t first = cur >> 8, present = cur & 0xffu;
-    const uint32_t leaves = __float_as_uint(S.recs[2 * (size_t)first + 1].w);
-    const bool nx = (bm.sign & 1u) != 0u, ny = (bm.sign & 2u) != 0u, nz = (bm.sign & 4u) != 0u;
-    uint32_t hit = 0;
-#pragma unroll
-    for (int h = 0; h < 8; h += kVisitBatch) {
-        float4 ra[kVisitBatch], rb[kVisitBatch];
-#pragma unroll
-        for (int k = 0; k < kVisitBatch; ++k) {
-            const uint32_t oct = (uint32_t)(h + k) ^ bm.sign;
-            const size_t idx = (size_t)first + (uint32_t)__popc(present & ((1u << oct) - 1u));
-            ra[k] = S.recs[2 * idx];
-            rb[k] = S.recs[2 * idx + 1];
-        }
-#pragma unroll
-        for (int k = 0; k < kVisitBatch; ++k) {
-            const float4 a = ra[k], b = rb[k];  // {min.xyz, max.x}, {max.y, max.z, w0, w1}
-            // a NaN (0 * inf, inf - inf) drops out of fmaxf / fminf: that bound then culls nothing
-            const float ex = fmaf(nx ? a.w : a.x, bm.inv_n.x, bm.c_n.x), xx = fmaf(nx ? a.x : a.w, bm.inv_f.x, bm.c_f.x);
-            const float ey = fmaf(ny ? b.x : a.y, bm.inv_n.y, bm.c_n.y), xy = fmaf(ny ? a.y : b.x, bm.inv_f.y, bm.c_f.y);
-            const float ez = fmaf(nz ? b.y : a.z, bm.inv_n.z, bm.c_n.z), xz = fmaf(nz ? a.z : b.y, bm.inv_f.z, bm.c_f.z);
-            const float lo = fmaxf(fmaxf(ex, ey), fmaxf(ez, bm.s0));
-            const float hi = fminf(fminf(xx, xy), fminf(xz, bm.s1));
-            hit |= lo <= hi ? (1u << (h + k)) : 0u;
-            ref[h + k] = __float_as_uint(b.z);
-        }
-        asm volatile("" ::: "memory");
-    }
-    uint32_t m = present | ((leaves & 0xffu) << 8);
-    const uint32_t s4 = bm.sign & 4u, s2 = bm.sign & 2u, s1 = bm.sign & 1u;
-    m = ((m >> s4) & 0x0f0fu) | ((m << s4) & 0xf0f0u);
-    m = ((m >> s2) & 0x3333u) | ((m << s2) & 0xccccu);
-    m = ((m >> s1) & 0x5555u) | ((m << s1) & 0xaaaau);
-    hit &= m;
-    *leaf_mask = hit & (m >> 8);
-    *inner_mask = hit & ~(m >> 8);
-}
-// true: no leaf box of the tree meets the beam.  Every lane of the wavefront calls it (live = this lane has a beam).
-// A walk that meets a leaf stops there and, if `resume` is given, leaves its state for the pair's rays: every block it
-// has been through held no leaf that the beam meets — so none that a ray of the pair could hit — and every inner child
-// the beam met is either visited already or still on its stack.  The rays therefore need not start at the root: they
-// resume at the block where the beam stopped, with the beam's stack (config 3, CPU simulation: 8.1 entries; 10.7
-// instead of 13.2 block visits per ray, the visits of inherited blocks that a ray then misses included).
-//   resume[0] = entries of the stack (kResumeRoot: start at the root instead), resume[1] = the block to enter,
-//   resume[2 ..] = the stack, bottom first; all as indices of quantised blocks.
-constexpr int kResumeWords = 16;
-constexpr int kResumeStack = kLdsStackDepth < kResumeWords - 2 ? kLdsStackDepth : kResumeWords - 2;  // entries handed over at most
-constexpr uint32_t kResumeRoot = 0xffffffffu;
-RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, const Beam& bm, uint32_t* cur_out, int* sp_out) {
-    uint32_t cur = S.root_ref;
-    int sp = 0;
-    bool walking = live, clear = true;
-    while (__ballot(walking) != 0ull) {
-        if (walking) {
-            uint32_t ref[8];
-            uint32_t leaf_mask = 0, inner_mask = 0;
-            beam_visit_block(S, cur, bm, ref, &leaf_mask, &inner_mask);
-            if (leaf_mask) { clear = false; walking = false; }
-            else walking = next_block(st, ref, inner_mask, &cur, &sp);
-        }
-    }
-    *cur_out = cur;  // where a walk that met a leaf stopped; its stack is st.get(0 .. sp - 1)
-    *sp_out = sp;
-    return clear;
-}
-// The state of a stopped beam walk, as the pair's rays will read it
-RT_DEV void write_resume(const DScene& S, const TraceStack& st, uint32_t cur, int sp, uint32_t* resume) {
-    if (sp <= kResumeStack) {
-        resume[0] = (uint32_t)sp;
-        resume[1] = S.block_of_first[cur >> 8];
-        for (int k = 0; k < sp; ++k) resume[2 + k] = S.block_of_first[st.get(k) >> 8];
-    } else {
-        resume[0] = kResumeRoot;
-    }
-}
-
 // ---- the shadow-ray walk over quantised blocks ------------------------------------------------
 // k_shadow is bound by the vector-memory path (TA busy 77-90 %, about one L1 access per clock and CU,
 // profiles/r02): a visit of the exact blocks issues 17 loads of 16 bytes per lane.  A shadow ray only asks
@@ -670,6 +592,99 @@ RT_DEV bool next_qblock(const TraceStack& st, const uint4& h1, uint32_t present,
     return true;
 }
 #endif
+
+// visit_qblock() for a beam: the slots whose quantised box the beam meets, in SLOT order (the quantised boxes enclose
+// the exact ones, so a miss here is a miss there)
+RT_DEV uint32_t beam_visit_qblock(const DScene& S, uint32_t blk, const Beam& bm, uint4* h1_out, uint32_t* present_out) {
+    const uint4* q = S.qblocks + 5 * (size_t)blk;
+    const uint4 h0 = q[0], h1 = q[1], qa = q[2], qb = q[3], qc = q[4];
+    const float ex = __uint_as_float((h0.w & 0xffu) << 23), ey = __uint_as_float((h0.w & 0xff00u) << 15), ez = __uint_as_float((h0.w & 0xff0000u) << 7);
+    // bound = (origin + q * step) * inv + c, entry and exit with their own inv and c (Beam)
+    const float snx = ex * bm.inv_n.x, sny = ey * bm.inv_n.y, snz = ez * bm.inv_n.z;
+    const float sfx = ex * bm.inv_f.x, sfy = ey * bm.inv_f.y, sfz = ez * bm.inv_f.z;
+    const float bnx = fmaf(__uint_as_float(h0.x), bm.inv_n.x, bm.c_n.x), bny = fmaf(__uint_as_float(h0.y), bm.inv_n.y, bm.c_n.y), bnz = fmaf(__uint_as_float(h0.z), bm.inv_n.z, bm.c_n.z);
+    const float bfx = fmaf(__uint_as_float(h0.x), bm.inv_f.x, bm.c_f.x), bfy = fmaf(__uint_as_float(h0.y), bm.inv_f.y, bm.c_f.y), bfz = fmaf(__uint_as_float(h0.z), bm.inv_f.z, bm.c_f.z);
+    const bool nx = (bm.sign & 1u) != 0u, ny = (bm.sign & 2u) != 0u, nz = (bm.sign & 4u) != 0u;
+    uint32_t near_[3][2], far_[3][2];
+    near_[0][0] = nx ? qb.z : qa.x; near_[0][1] = nx ? qb.w : qa.y; far_[0][0] = nx ? qa.x : qb.z; far_[0][1] = nx ? qa.y : qb.w;
+    near_[1][0] = ny ? qc.x : qa.z; near_[1][1] = ny ? qc.y : qa.w; far_[1][0] = ny ? qa.z : qc.x; far_[1][1] = ny ? qa.w : qc.y;
+    near_[2][0] = nz ? qc.z : qb.x; near_[2][1] = nz ? qc.w : qb.y; far_[2][0] = nz ? qb.x : qc.z; far_[2][1] = nz ? qb.y : qc.w;
+    uint32_t miss = 0;
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+        const int w = k >> 2, b = k & 3;
+        // a NaN (0 * inf, inf - inf) drops out of fmaxf / fminf: that bound then culls nothing
+        const float lo = fmaxf(fmaxf(fmaf(qbyte(near_[0][w], b), snx, bnx), fmaf(qbyte(near_[1][w], b), sny, bny)),
+                               fmaxf(fmaf(qbyte(near_[2][w], b), snz, bnz), bm.s0));
+        const float hi = fminf(fminf(fmaf(qbyte(far_[0][w], b), sfx, bfx), fmaf(qbyte(far_[1][w], b), sfy, bfy)),
+                               fminf(fmaf(qbyte(far_[2][w], b), sfz, bfz), bm.s1));
+        miss = (miss << 1) | (lo <= hi ? 0u : 1u);
+    }
+    *h1_out = h1;
+    *present_out = h0.w >> 24;
+    return ~miss & (h0.w >> 24);
+}
+// the beam against the EXACT box of child record `rec`
+RT_DEV bool beam_meets_record(const DScene& S, uint32_t rec, const Beam& bm) {
+    const float4 a = S.recs[2 * (size_t)rec], b = S.recs[2 * (size_t)rec + 1];  // {min.xyz, max.x}, {max.y, max.z, w0, w1}
+    const bool nx = (bm.sign & 1u) != 0u, ny = (bm.sign & 2u) != 0u, nz = (bm.sign & 4u) != 0u;
+    const float ex = fmaf(nx ? a.w : a.x, bm.inv_n.x, bm.c_n.x), xx = fmaf(nx ? a.x : a.w, bm.inv_f.x, bm.c_f.x);
+    const float ey = fmaf(ny ? b.x : a.y, bm.inv_n.y, bm.c_n.y), xy = fmaf(ny ? a.y : b.x, bm.inv_f.y, bm.c_f.y);
+    const float ez = fmaf(nz ? b.y : a.z, bm.inv_n.z, bm.c_n.z), xz = fmaf(nz ? a.z : b.y, bm.inv_f.z, bm.c_f.z);
+    const float lo = fmaxf(fmaxf(ex, ey), fmaxf(ez, bm.s0));
+    const float hi = fminf(fminf(xx, xy), fminf(xz, bm.s1));
+    return lo <= hi;
+}
+// true: no leaf box of the tree meets the beam.  Every lane of the wavefront calls it (live = this lane has a beam).
+// The walk goes over the quantised blocks (5 loads per visit); a leaf whose quantised box the beam meets is checked
+// against its exact box (the quantised box of a wall's flat triangle is thick enough to be met by a beam that leaves
+// the wall).  A walk that meets a leaf stops there and leaves its state for the pair's rays: every block it has been
+// through held no leaf that the beam meets — so none that a ray of the pair could hit — and every inner child the beam
+// met is either visited already or still on its stack.  The rays therefore need not start at the root: they resume at
+// the block where the beam stopped, with the beam's stack (config 3, CPU simulation: 8.1 entries; 10.7 instead of 13.2
+// block visits per ray, the visits of inherited blocks that a ray then misses included; 7.7 with those filtered out).
+//   resume[0] = entries of the stack (kResumeRoot: start at the root instead), resume[1] = the block to enter,
+//   resume[2 ..] = the stack, bottom first; all as indices of quantised blocks.
+constexpr int kResumeWords = 16;
+constexpr int kResumeStack = kLdsStackDepth < kResumeWords - 2 ? kLdsStackDepth : kResumeWords - 2;  // entries handed over at most
+constexpr uint32_t kResumeRoot = 0xffffffffu;
+RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, const Beam& bm, uint32_t* cur_out, int* sp_out) {
+    uint32_t cur = 0u;  // block index; the root is block 0
+    int sp = 0;
+    bool walking = live, clear = true;
+    while (__ballot(walking) != 0ull) {
+        if (walking) {
+            uint4 h1;
+            uint32_t present;
+            const uint32_t hit = beam_visit_qblock(S, cur, bm, &h1, &present);
+            uint32_t leaf_hits = hit & (h1.x >> 24);
+            bool met = false;
+            if (leaf_hits) {
+                const uint32_t first = S.block_first[cur];
+                while (leaf_hits && !met) {
+                    const int k = __ffs((int)leaf_hits) - 1;
+                    leaf_hits &= leaf_hits - 1u;
+                    met = beam_meets_record(S, first + (uint32_t)__popc(present & ((1u << k) - 1u)), bm);
+                }
+            }
+            if (met) { clear = false; walking = false; }
+            else walking = next_qblock(st, h1, present, hit & ~(h1.x >> 24), bm.sign, &cur, &sp);
+        }
+    }
+    *cur_out = cur;  // where a walk that met a leaf stopped; its stack is st.get(0 .. sp - 1)
+    *sp_out = sp;
+    return clear;
+}
+// The state of a stopped beam walk, as the pair's rays will read it
+RT_DEV void write_resume(const TraceStack& st, uint32_t cur, int sp, uint32_t* resume) {
+    if (sp <= kResumeStack) {
+        resume[0] = (uint32_t)sp;
+        resume[1] = cur;
+        for (int k = 0; k < sp; ++k) resume[2 + k] = st.get(k);
+    } else {
+        resume[0] = kResumeRoot;
+    }
+}
 
 // Inclusive scans over the 64 lanes of a wavefront through the DPP path (shifts within rows of 16 lanes,
 // then the last lane of a row broadcast to the rows after it); every lane of the wavefront must be active.

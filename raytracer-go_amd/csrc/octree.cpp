@@ -650,7 +650,7 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
     out->records.clear();
     out->qblocks.clear();
     out->order.clear();
-    out->block_of_first.assign(1, 0u);
+    out->block_first.assign(1, 0u);
     out->block_box.clear();
     out->root_ref = 0; out->n_inner = 0; out->depth = 0; out->stack_bound = 1;
     if (nodes.empty() || nodes[0].empty) {  // no shapes: present mask 0 => every ray misses
@@ -688,7 +688,7 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
         out->root_ref = (0u << 8) | 1u;
         out->n_inner = 1; out->depth = 1; out->stack_bound = 8;
         append_qblock(out, 0, 1, 1u, 1u, 0u);
-        out->block_of_first.assign(2, 0u);
+        out->block_first.assign(1, 0u);
         out->block_box.assign(8, 0.0f);
         for (int a = 0; a < 3; ++a) { out->block_box[(size_t)a] = r.bmin[a]; out->block_box[(size_t)(4 + a)] = r.bmax[a]; }
         return true;
@@ -734,10 +734,10 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
         out->n_inner++;
         if (p.level > out->depth) out->depth = p.level;
     }
-    out->block_of_first.assign(out->records.size() + 1, 0u);
+    out->block_first.assign(blocks.size(), 0u);
     out->block_box.assign(blocks.size() * 8, 0.0f);
     for (size_t i = 0; i < blocks.size(); ++i) {
-        out->block_of_first[(size_t)blocks[i].first] = (uint32_t)i;
+        out->block_first[i] = (uint32_t)blocks[i].first;
         float* bb = out->block_box.data() + i * 8;
         const ChildRecord* rec = out->records.data() + blocks[i].first;
         for (int a = 0; a < 3; ++a) {

@@ -103,7 +103,7 @@ struct FlatTree {
     std::vector<uint32_t> qblocks;  // kQBlockWords per block, block i of the breadth-first order (root = 0)
     std::vector<int32_t> order;  // re-ordered shape q -> index in Scene.Shapes
     std::vector<float> block_box;  // per block: {min.xyz, 0, max.xyz, 0} of its children's fp32 boxes (what a ray must meet to hit anything below the block)
-    std::vector<uint32_t> block_of_first;  // first child record of a block -> the block's index (other entries 0); one entry per record + 1
+    std::vector<uint32_t> block_first;  // per block: its first child record
     uint32_t root_ref = 0;  // (first << 8) | present of the root block
     int64_t n_inner = 0;    // blocks
     int32_t depth = 0;      // levels of blocks below the root (root block = 1)

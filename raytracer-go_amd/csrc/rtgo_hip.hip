@@ -438,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_beam(DScene S, Batch B, Work Wk
             Wk.pair_seg[at] = hl;
             if (Wk.beam_state) {  // the walk's stack is still in place (LDS + spill region) until the next round
                 uint32_t* dst = Wk.beam_state + (size_t)at * kResumeWords;
-                if (judge) write_resume(S, st, stop_block, stop_sp, dst); else dst[0] = kResumeRoot;
+                if (judge) write_resume(st, stop_block, stop_sp, dst); else dst[0] = kResumeRoot;
             }
         }
     }
@@ -781,7 +781,7 @@ constexpr int kLanes = 4;
 struct rt_scene {
     int device = 0;
     DScene d{};
-    void* d_recs = nullptr; void* d_qblocks = nullptr; void* d_prims = nullptr; void* d_tprims = nullptr; void* d_prim_ids = nullptr; void* d_block_of_first = nullptr; void* d_block_box = nullptr; void* d_mats = nullptr; void* d_texs = nullptr; void* d_lights = nullptr;
+    void* d_recs = nullptr; void* d_qblocks = nullptr; void* d_prims = nullptr; void* d_tprims = nullptr; void* d_prim_ids = nullptr; void* d_block_first = nullptr; void* d_block_box = nullptr; void* d_mats = nullptr; void* d_texs = nullptr; void* d_lights = nullptr;
     std::vector<void*> d_tex_pixels;
     rt_scene_info info{};
     double ms_build = 0;
@@ -1194,8 +1194,8 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     HIP_TRY_S(hipMemcpy(s->d_tprims, tprims.data(), tprims.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_prim_ids, (flat.order.size() + 1) * sizeof(int32_t)));
     if (!flat.order.empty()) HIP_TRY_S(hipMemcpy(s->d_prim_ids, flat.order.data(), flat.order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY_S(hipMalloc(&s->d_block_of_first, flat.block_of_first.size() * sizeof(uint32_t)));
-    HIP_TRY_S(hipMemcpy(s->d_block_of_first, flat.block_of_first.data(), flat.block_of_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_block_first, flat.block_first.size() * sizeof(uint32_t)));
+    HIP_TRY_S(hipMemcpy(s->d_block_first, flat.block_first.data(), flat.block_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_block_box, flat.block_box.size() * sizeof(float)));
     HIP_TRY_S(hipMemcpy(s->d_block_box, flat.block_box.data(), flat.block_box.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_mats, mats.size() * sizeof(DMaterial)));
@@ -1210,7 +1210,7 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     const int spill = flat.stack_bound + 1 > kLdsStackDepth ? flat.stack_bound + 1 - kLdsStackDepth : 0;  // +1: the nearest child is pushed, then popped
     s->spill = spill;  // the region itself is sized by ensure_overflow() for the grids a call really launches
 
-    s->d.recs = (const float4*)s->d_recs; s->d.qblocks = (const uint4*)s->d_qblocks; s->d.prims = (const float4*)s->d_prims; s->d.tprims = (const float4*)s->d_tprims; s->d.prim_ids = (const int*)s->d_prim_ids; s->d.block_of_first = (const uint32_t*)s->d_block_of_first; s->d.block_box = (const float4*)s->d_block_box;
+    s->d.recs = (const float4*)s->d_recs; s->d.qblocks = (const uint4*)s->d_qblocks; s->d.prims = (const float4*)s->d_prims; s->d.tprims = (const float4*)s->d_tprims; s->d.prim_ids = (const int*)s->d_prim_ids; s->d.block_first = (const uint32_t*)s->d_block_first; s->d.block_box = (const float4*)s->d_block_box;
     s->d.materials = (const DMaterial*)s->d_mats; s->d.textures = (const DTexture*)s->d_texs;
     s->d.lights = (const DLight*)s->d_lights;
     s->d.n_lights = (int)desc->n_lights; s->d.n_pos_lights = n_pos; s->d.root_ref = flat.root_ref;
@@ -1257,7 +1257,7 @@ void rt_scene_destroy(rt_scene* s) {
     }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     for (auto& e : s->ev_wall) if (e) (void)hipEventDestroy(e);
-    void* ptrs[] = {s->d_recs, s->d_qblocks, s->d_prims, s->d_tprims, s->d_prim_ids, s->d_block_of_first, s->d_block_box, s->d_mats, s->d_texs, s->d_lights};
+    void* ptrs[] = {s->d_recs, s->d_qblocks, s->d_prims, s->d_tprims, s->d_prim_ids, s->d_block_first, s->d_block_box, s->d_mats, s->d_texs, s->d_lights};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : s->d_tex_pixels) (void)hipFree(p);
     for (DevBuf* b : {&s->accum, &s->rgba, &s->probe_in, &s->probe_out, &s->probe_out2}) b->release();
