@@ -1499,14 +1499,18 @@ static int rt_render_accum_device_impl(rt_scene* s, const rt_image_spec* spec, c
     n_lanes = n_lanes < 1 ? 1 : (n_lanes > kLanes ? kLanes : n_lanes);
     const long long n_batches = (P.n_local_pixels + P.pix_per_batch - 1) / P.pix_per_batch;
     if (n_batches < n_lanes) n_lanes = (int)n_batches;
-    // the widest launch is k_shadow's: one lane per (pair, repetition lane), at most 64 lanes per pair
-    for (int l = 0; l < n_lanes; ++l) {
-        rc = ensure_work(s, s->lanes[l], P.batch_paths, spec->ray_tracing_max_depth, s->d.n_pos_lights,
-                         (unsigned long long)P.batch_paths * (unsigned long long)std::max(1, s->d.n_pos_lights) * 64ull);
-        if (rc != RT_OK) return rc;
-    }
+    // a lane's workspace (made on first use, by the lane's own thread: the allocations of a first frame run side by
+    // side); the widest launch is k_shadow's: one lane per (pair, repetition lane), at most 64 lanes per pair
+    auto workspace = [&](int l) {
+        return ensure_work(s, s->lanes[l], P.batch_paths, spec->ray_tracing_max_depth, s->d.n_pos_lights,
+                           (unsigned long long)P.batch_paths * (unsigned long long)std::max(1, s->d.n_pos_lights) * 64ull);
+    };
     hipStream_t stream = (hipStream_t)hip_stream;
-    if (n_lanes == 1) return run_render(s, s->lanes[0], s->lanes[0].arena, spec, P, d_accum, stream, stats, true);
+    if (n_lanes == 1) {
+        rc = workspace(0);
+        if (rc != RT_OK) return rc;
+        return run_render(s, s->lanes[0], s->lanes[0].arena, spec, P, d_accum, stream, stats, true);
+    }
     // fork: the other lanes start behind what the caller has queued on its stream (the zeroing of d_accum, say)
     if (stats) HIP_TRY(hipEventRecord(s->ev_wall[0], stream));
     HIP_TRY(hipEventRecord(s->ev_fork, stream));
@@ -1516,6 +1520,8 @@ static int rt_render_accum_device_impl(rt_scene* s, const rt_image_spec* spec, c
     rc = on_every_rank(n_lanes, [&](int l) -> int {
         Lane& ln = s->lanes[l];
         HIP_TRY(hipSetDevice(device));
+        const int wrc = workspace(l);
+        if (wrc != RT_OK) return wrc;
         hipStream_t st = l == 0 ? stream : ln.stream;
         if (l > 0) HIP_TRY(hipStreamWaitEvent(st, s->ev_fork, 0));
         const int r = run_render(s, ln, ln.arena, spec, P, d_accum, st, stats ? &part_stats[(size_t)l] : nullptr, true, l, n_lanes, s->ev_wall[0], &spans[(size_t)l]);
