@@ -1368,9 +1368,11 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
     if (n_ctr > ln.h_counter_words) return fail(RT_ERR_LIMIT, "RayTracingMaxDepth exceeds the counter snapshots of this scene");
     const bool timed = stats != nullptr;
     // pair beams: on for scenes of 256 shapes or more (the README scene's 11 shapes: 8.9 ms per frame without, 10.5 with;
-    // a walk through two blocks is cheaper than proving it unnecessary).  RTGO_BEAM=0 / 1 forces them off / on.
+    // a walk through two blocks is cheaper than proving it unnecessary) and 4 repetitions or more (a beam's walk costs
+    // about a ray's: config 2 at 1080p 16 spp with 1 repetition 9.1 ms without, 10.1 with; with 16 repetitions 20.4 and
+    // 15.7).  RTGO_BEAM=0 / 1 forces them off / on.
     const char* beam_env = std::getenv("RTGO_BEAM");
-    const bool beams = beam_env ? beam_env[0] != '0' : s->info.n_shapes >= 256;
+    const bool beams = beam_env ? beam_env[0] != '0' : (s->info.n_shapes >= 256 && reps >= 4);
     const char* resume_env = std::getenv("RTGO_RESUME");  // "0": rays start at the root, not where their pair's beam stopped (A/B switch)
     const bool resume_on = !(resume_env && resume_env[0] == '0');
     const bool staged = timed && may_create_events;  // per-stage events (and their host-side list) only where the entry point may allocate
