@@ -1342,10 +1342,10 @@ static int plan_render(const rt_scene* s, const rt_image_spec* spec, const rt_pa
         const long long tt = (long long)tile * tile;
         const long long n_tiles = P->n_local_pixels / tt;
         const long long n_batches = (P->n_local_pixels + P->pix_per_batch - 1) / P->pix_per_batch;
-        if (n_batches < kLanes && n_tiles >= kLanes) {
-            const long long per = ((n_tiles + kLanes - 1) / kLanes) * tt;
-            if (per * P->ns_max >= ((long long)1 << 20)) P->pix_per_batch = per;
-        }
+        int target = kLanes;  // batches wanted at least (RTGO_MIN_BATCHES: developer knob)
+        if (const char* ev = std::getenv("RTGO_MIN_BATCHES")) target = std::max(1, std::atoi(ev));
+        while (target > 1 && (n_tiles < target || ((n_tiles + target - 1) / target) * tt * P->ns_max < ((long long)1 << 20))) --target;
+        if (n_batches < target) P->pix_per_batch = ((n_tiles + target - 1) / target) * tt;
     }
     P->batch_paths = (int64_t)std::min<long long>(P->pix_per_batch, P->n_local_pixels) * P->ns_max;
     return RT_OK;
