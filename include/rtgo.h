@@ -163,7 +163,11 @@ typedef struct rt_scene rt_scene; /* opaque: flattened tree + tables resident in
  * the reference's error behaviour (accelerationstructures.go:73, example.go:36-44). */
 const char* rt_last_error(void);
 
-/* Library / device probe.  Fails (RT_ERR_DEVICE) when no HIP device is visible. */
+/* Library / device probe.  Fails (RT_ERR_DEVICE) when no HIP device is visible.
+ * Optional (rt_scene_create calls it), but worth calling FIRST, before the caller flattens its scene into an
+ * rt_scene_desc: the first call for a device starts, on a thread of the library's own, the HIP runtime's
+ * one-time copy-path set-up (about 0.15 s in a fresh process), which rt_scene_create otherwise has only its
+ * tree build to hide behind; rt_scene_create waits for that thread before its first upload. */
 int rt_init(int device);
 
 /* Replaces NewBoundingVolumeHierarchy(&scene.Shapes) (accelerationstructures.go:27-65,

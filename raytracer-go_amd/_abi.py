@@ -170,40 +170,31 @@ class FlatScene:
             materials.append(rm)
             return mat_index[key]
 
-        chunks = []
-        pending = []
-
-        def flush():
-            if not pending:
-                return
-            arr = np.zeros(len(pending), dtype=SHAPE_DTYPE)
-            for i, s in enumerate(pending):
-                r = arr[i]
-                if isinstance(s, api.Sphere):
-                    r["kind"] = RT_SHAPE_SPHERE
-                    r["a"] = (s.Center.X, s.Center.Y, s.Center.Z)
-                    r["b"] = (s.Radius, 0.0, 0.0)
-                elif isinstance(s, api.TrianglePlane):
-                    r["kind"] = RT_SHAPE_TRIANGLE
-                    r["single_sided"] = 1 if s.SingleSided else 0
-                    r["a"] = (s.PointA.X, s.PointA.Y, s.PointA.Z)
-                    r["b"] = (s.PointB.X, s.PointB.Y, s.PointB.Z)
-                    r["c"] = (s.PointC.X, s.PointC.Y, s.PointC.Z)
-                else:
-                    raise TypeError(f"unknown shape type {type(s).__name__}")
-                r["material"] = material_id(s.Mat)
-            chunks.append(arr)
-            pending.clear()
-
+        # one table for all shapes: meshes write their records straight into their slice of it
+        total = sum(len(s) if isinstance(s, api.TriangleMesh) else 1 for s in scene.Shapes)
+        table = np.zeros(total, dtype=SHAPE_DTYPE)
+        at = 0
         for s in scene.Shapes:
             if isinstance(s, api.TriangleMesh):
-                flush()
-                chunks.append(s.to_records(material_id(s.Mat)))
+                s.to_records(material_id(s.Mat), out=table[at:at + len(s)])
+                at += len(s)
+                continue
+            r = table[at]
+            if isinstance(s, api.Sphere):
+                r["kind"] = RT_SHAPE_SPHERE
+                r["a"] = (s.Center.X, s.Center.Y, s.Center.Z)
+                r["b"] = (s.Radius, 0.0, 0.0)
+            elif isinstance(s, api.TrianglePlane):
+                r["kind"] = RT_SHAPE_TRIANGLE
+                r["single_sided"] = 1 if s.SingleSided else 0
+                r["a"] = (s.PointA.X, s.PointA.Y, s.PointA.Z)
+                r["b"] = (s.PointB.X, s.PointB.Y, s.PointB.Z)
+                r["c"] = (s.PointC.X, s.PointC.Y, s.PointC.Z)
             else:
-                pending.append(s)
-        flush()
-        self.shapes = np.concatenate(chunks) if chunks else np.zeros(0, dtype=SHAPE_DTYPE)
-        self.shapes = np.ascontiguousarray(self.shapes)
+                raise TypeError(f"unknown shape type {type(s).__name__}")
+            r["material"] = material_id(s.Mat)
+            at += 1
+        self.shapes = table
 
         lights = []
         for l in scene.Lights:

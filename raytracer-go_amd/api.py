@@ -215,15 +215,13 @@ class TriangleMesh:
         x, z = (x * math.cos(k * rv.Y) + z * math.sin(k * rv.Y), -1 * x * math.sin(k * rv.Y) + z * math.cos(k * rv.Y))
         self.vertices = np.ascontiguousarray(np.stack([x, y, z], axis=-1))
 
-    def to_records(self, material_index):
-        rec = np.zeros(len(self), dtype=_abi.SHAPE_DTYPE)
-        rec["kind"] = _abi.RT_SHAPE_TRIANGLE
-        rec["material"] = material_index
-        rec["single_sided"] = 1 if self.SingleSided else 0
-        for name, k in (("a", 0), ("b", 1), ("c", 2)):
-            rec[name]["x"] = self.vertices[:, k, 0]
-            rec[name]["y"] = self.vertices[:, k, 1]
-            rec[name]["z"] = self.vertices[:, k, 2]
+    def to_records(self, material_index, out=None):
+        """The mesh as rt_shape records (into `out`, a slice of the scene's table, when given)."""
+        n = len(self)
+        rec = np.empty(n, dtype=_abi.SHAPE_DTYPE) if out is None else out
+        # a record is 4 int32 {kind, material, single_sided, pad} and 9 doubles {a, b, c}: one strided copy each
+        rec.view(np.int32).reshape(n, -1)[:, :4] = (_abi.RT_SHAPE_TRIANGLE, material_index, 1 if self.SingleSided else 0, 0)
+        rec.view(np.float64).reshape(n, -1)[:, 2:] = self.vertices.reshape(n, 9)
         return rec
 
 

@@ -85,6 +85,7 @@ class DeviceScene:
 
     def __init__(self, scene, device=0):
         self._h = C.c_void_p()
+        _check(lib().rt_init(device))  # first: the runtime's start-up then runs under the flattening below (rtgo.h)
         self._flat = _abi.FlatScene(scene)
         _check(lib().rt_scene_create(C.addressof(self._flat.desc), device, C.byref(self._h)))
         self.device = device
@@ -188,6 +189,8 @@ class MultiDeviceScene:
 
     def __init__(self, scene, devices):
         self._h = C.c_void_p()
+        for d in devices:  # first: the runtime's start-up then runs under the flattening below (rtgo.h)
+            _check(lib().rt_init(d))
         self._flat = _abi.FlatScene(scene)
         self.devices = (C.c_int32 * len(devices))(*devices)
         _check(lib().rt_multi_create(C.addressof(self._flat.desc), self.devices, len(devices), C.byref(self._h)))

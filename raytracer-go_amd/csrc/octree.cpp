@@ -13,6 +13,8 @@
 #include <atomic>
 #include <memory>
 #include <thread>
+#include <chrono>
+#include <cstdio>
 
 namespace rtgo {
 namespace {
@@ -71,7 +73,7 @@ int octant_of(const rt_shape& s, const HostNode& cell, Jitter& rng) {
 }
 
 // splitBvhQuadrant: accelerationstructures.go:282-353
-void split_cell(std::vector<HostNode>& nodes, int32_t at) {
+void split_cell(HostNodes& nodes, int32_t at) {
     const int32_t base = (int32_t)nodes.size();
     double lo[3], hi[3], half[3];
     for (int a = 0; a < 3; ++a) {
@@ -102,7 +104,7 @@ float round_up_f32(double x) {
 }
 
 // Skip nodes that have exactly one non-empty child (same box as that child after the refit).
-int32_t skip_chain(const std::vector<HostNode>& nodes, int32_t n) {
+int32_t skip_chain(const HostNodes& nodes, int32_t n) {
     while (nodes[n].child_base >= 0) {
         int32_t only = -1, cnt = 0;
         for (int o = 0; o < 8; ++o) {
@@ -118,8 +120,8 @@ int32_t skip_chain(const std::vector<HostNode>& nodes, int32_t n) {
 }  // namespace
 
 constexpr int kMaxOctreeLevels = 1300;
-std::vector<HostNode> build_octree(const rt_shape* shapes, int64_t n) {
-    std::vector<HostNode> nodes;
+HostNodes build_octree(const rt_shape* shapes, int64_t n) {
+    HostNodes nodes;
     nodes.reserve((size_t)(n * 4 + 16));
     HostNode root;
     // accelerationstructures.go:29-42: union of all shape bounds, widened by the max jitter
@@ -186,7 +188,7 @@ std::vector<HostNode> build_octree(const rt_shape* shapes, int64_t n) {
 
 // ---- binned-SAH BVH emitted in the same 8-slot HostNode form (the default tree; spec in octree.hpp) ----
 namespace {
-struct SahItem { double lo[3], hi[3], c[3]; int32_t shape; };
+struct SahItem { double lo[3], hi[3]; int32_t shape; };  // centroid = (lo + hi) * 0.5, recomputed where needed
 struct Bvh2 { double lo[3], hi[3]; int32_t left, right, b, e; };
 double area3(const double lo[3], const double hi[3]) {
     const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
@@ -196,8 +198,17 @@ constexpr int kMaxSahDepth = 48;
 constexpr int32_t kParallelMin = 16384;  // ranges at least this long may be split off to a thread of their own
 constexpr int32_t kChunkMin = 131072;    // ranges at least this long are swept by several threads
 struct SahBuilder {
-    std::vector<SahItem> items;
-    std::unique_ptr<SahItem[]> tmp;    // same length as items: a range's right half while it is being split
+    // min / max of finite numbers as one instruction each (std::fmin's NaN rule costs three).  The items' coordinates
+    // are finite (checked at scene creation) and no -0 is among them (build_sah), so which argument an equal pair
+    // returns cannot be seen and merging the chunks' minima in any order gives the same bits.
+    static double mn(double a, double b) { return b < a ? b : a; }
+    static double mx(double a, double b) { return b > a ? b : a; }
+    // The items live in two arrays of the same length.  A range is split by ONE sweep that reads it in the array it is
+    // in and writes its left and right halves, each in the old order, to the same range of the other array (a long
+    // range streams through memory once per level instead of three times: the top levels are bound by that), and
+    // gathers the halves' bounds on the way, which the children would otherwise sweep for.  A leaf's items end up in
+    // buf[0], where emit() reads them.
+    std::unique_ptr<SahItem[]> buf[2];
     std::unique_ptr<Bvh2[]> b2;        // 2n - 1 nodes at most (every leaf holds a shape); numbered as they are made
     std::atomic<int32_t> n_nodes{0};
     int leaf_size;
@@ -208,9 +219,26 @@ struct SahBuilder {
     // emit() follows left/right links, so the tree that comes out is the same for any number of threads.
     static constexpr int kBins = 16;
     struct Bin { double lo[3], hi[3]; int n; };
-    struct Pass {  // what one chunk of a range contributes to the passes over it
+    struct Box {  // of a range: its items' bounds and their centroids' bounds
         double lo[3], hi[3], clo[3], chi[3];
+        void clear() { for (int a = 0; a < 3; ++a) { lo[a] = clo[a] = DBL_MAX; hi[a] = chi[a] = -DBL_MAX; } }
+        void add(const SahItem& it) {
+            for (int a = 0; a < 3; ++a) {
+                const double c = (it.lo[a] + it.hi[a]) * 0.5;
+                lo[a] = mn(lo[a], it.lo[a]); hi[a] = mx(hi[a], it.hi[a]);
+                clo[a] = mn(clo[a], c); chi[a] = mx(chi[a], c);
+            }
+        }
+        void add(const Box& o) {  // min and max merge exactly: chunking a sweep changes no value
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = mn(lo[a], o.lo[a]); hi[a] = mx(hi[a], o.hi[a]);
+                clo[a] = mn(clo[a], o.clo[a]); chi[a] = mx(chi[a], o.chi[a]);
+            }
+        }
+    };
+    struct Pass {  // what one chunk of a range contributes to the sweeps over it
         Bin bins[3][kBins];
+        Box left, right;
         int32_t n_left;
     };
     // f(chunk, first, last) over nt equal chunks of [b, e), chunk 0 on the calling thread
@@ -224,37 +252,38 @@ struct SahBuilder {
         f(0, b, b + (int32_t)(len / nt));
         group.join();
     }
-    int32_t build(int32_t b, int32_t e, int depth, int threads) {
-        // a long range is swept by all the threads this subtree may use; min, max and counts merge exactly,
-        // so the chunking changes no value
+    Box range_box(int32_t b, int32_t e, int threads) const {  // of the whole input; every other range gets its box from its parent's sweep
         const int nt = (e - b >= kChunkMin) ? threads : 1;
+        std::vector<Box> part((size_t)nt);
+        const SahItem* items = buf[0].get();
+        chunks(b, e, nt, [&](int c, int32_t cb, int32_t ce) {
+            Box bx; bx.clear();
+            for (int32_t i = cb; i < ce; ++i) bx.add(items[i]);
+            part[(size_t)c] = bx;
+        });
+        Box all; all.clear();
+        for (const Box& p : part) all.add(p);
+        return all;
+    }
+    // the subtree of the range [b, e) of buf[in]; bx = the range's box
+    int32_t build(int32_t b, int32_t e, int depth, int threads, int in, const Box& bx) {
+        const int nt = (e - b >= kChunkMin) ? threads : 1;
+        Bvh2 nd;
+        nd.b = b; nd.e = e; nd.left = nd.right = -1;
+        for (int a = 0; a < 3; ++a) { nd.lo[a] = bx.lo[a]; nd.hi[a] = bx.hi[a]; }
+        const double* clo = bx.clo; const double* chi = bx.chi;
+        const int32_t me = n_nodes.fetch_add(1, std::memory_order_relaxed);
+        b2[me] = nd;
+        if (e - b <= leaf_size) {
+            if (in != 0) std::copy(buf[1].get() + b, buf[1].get() + e, buf[0].get() + b);
+            return me;
+        }
+        const SahItem* items = buf[in].get();
+
         Pass one;
         std::vector<Pass> many;
         Pass* ps = &one;
         if (nt > 1) { many.resize((size_t)nt); ps = many.data(); }
-
-        chunks(b, e, nt, [&](int c, int32_t cb, int32_t ce) {
-            Pass& p = ps[c];
-            for (int a = 0; a < 3; ++a) { p.lo[a] = p.clo[a] = DBL_MAX; p.hi[a] = p.chi[a] = -DBL_MAX; }
-            for (int32_t i = cb; i < ce; ++i)
-                for (int a = 0; a < 3; ++a) {
-                    p.lo[a] = std::fmin(p.lo[a], items[i].lo[a]); p.hi[a] = std::fmax(p.hi[a], items[i].hi[a]);
-                    p.clo[a] = std::fmin(p.clo[a], items[i].c[a]); p.chi[a] = std::fmax(p.chi[a], items[i].c[a]);
-                }
-        });
-        Bvh2 nd;
-        nd.b = b; nd.e = e; nd.left = nd.right = -1;
-        double clo[3], chi[3];
-        for (int a = 0; a < 3; ++a) { nd.lo[a] = clo[a] = DBL_MAX; nd.hi[a] = chi[a] = -DBL_MAX; }
-        for (int c = 0; c < nt; ++c)
-            for (int a = 0; a < 3; ++a) {
-                nd.lo[a] = std::fmin(nd.lo[a], ps[c].lo[a]); nd.hi[a] = std::fmax(nd.hi[a], ps[c].hi[a]);
-                clo[a] = std::fmin(clo[a], ps[c].clo[a]); chi[a] = std::fmax(chi[a], ps[c].chi[a]);
-            }
-        const int32_t me = n_nodes.fetch_add(1, std::memory_order_relaxed);
-        b2[me] = nd;
-        if (e - b <= leaf_size) return me;
-
         bool use[3]; double scale[3];
         bool any = false;
         for (int a = 0; a < 3; ++a) {
@@ -273,93 +302,101 @@ struct SahBuilder {
                 for (int32_t i = cb; i < ce; ++i)
                     for (int a = 0; a < 3; ++a) {
                         if (!use[a]) continue;
-                        int k = (int)((items[i].c[a] - clo[a]) * scale[a]);  // coordinates are finite (checked at scene creation)
+                        int k = (int)(((items[i].lo[a] + items[i].hi[a]) * 0.5 - clo[a]) * scale[a]);  // coordinates are finite (checked at scene creation)
                         if (k >= kBins) k = kBins - 1;
                         if (k < 0) k = 0;
                         Bin& bn = p.bins[a][k];
                         bn.n++;
-                        for (int q = 0; q < 3; ++q) { bn.lo[q] = std::fmin(bn.lo[q], items[i].lo[q]); bn.hi[q] = std::fmax(bn.hi[q], items[i].hi[q]); }
+                        for (int q = 0; q < 3; ++q) { bn.lo[q] = mn(bn.lo[q], items[i].lo[q]); bn.hi[q] = mx(bn.hi[q], items[i].hi[q]); }
                     }
             });
             for (int a = 0; a < 3; ++a) {
                 if (!use[a]) continue;
-                Bin* bins = ps[0].bins[a];
+                Bin bins[kBins];  // the chunks' bins merged (theirs are kept: a chunk's own counts place its items below)
+                for (int k = 0; k < kBins; ++k) bins[k] = ps[0].bins[a][k];
                 for (int c = 1; c < nt; ++c)
                     for (int k = 0; k < kBins; ++k) {
                         const Bin& o = ps[c].bins[a][k];
                         bins[k].n += o.n;
-                        for (int q = 0; q < 3; ++q) { bins[k].lo[q] = std::fmin(bins[k].lo[q], o.lo[q]); bins[k].hi[q] = std::fmax(bins[k].hi[q], o.hi[q]); }
+                        for (int q = 0; q < 3; ++q) { bins[k].lo[q] = mn(bins[k].lo[q], o.lo[q]); bins[k].hi[q] = mx(bins[k].hi[q], o.hi[q]); }
                     }
                 double ra[kBins]; int rn[kBins];
                 double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+                // an empty bin changes neither side's box nor count: the boundary behind it costs what the one before it
+                // does and cannot win (strictly smaller wins), so most of a short range's 16 bins are passed over
                 int cnt = 0;
+                double area = 0;
                 for (int k = kBins - 1; k >= 1; --k) {
-                    for (int q = 0; q < 3; ++q) { lo[q] = std::fmin(lo[q], bins[k].lo[q]); hi[q] = std::fmax(hi[q], bins[k].hi[q]); }
-                    cnt += bins[k].n;
-                    ra[k] = cnt ? area3(lo, hi) : 0; rn[k] = cnt;
+                    if (bins[k].n) {
+                        for (int q = 0; q < 3; ++q) { lo[q] = mn(lo[q], bins[k].lo[q]); hi[q] = mx(hi[q], bins[k].hi[q]); }
+                        cnt += bins[k].n;
+                        area = area3(lo, hi);
+                    }
+                    ra[k] = area; rn[k] = cnt;
                 }
                 for (int q = 0; q < 3; ++q) { lo[q] = DBL_MAX; hi[q] = -DBL_MAX; }
                 cnt = 0;
                 for (int k = 0; k < kBins - 1; ++k) {
-                    for (int q = 0; q < 3; ++q) { lo[q] = std::fmin(lo[q], bins[k].lo[q]); hi[q] = std::fmax(hi[q], bins[k].hi[q]); }
+                    if (bins[k].n == 0) continue;
+                    for (int q = 0; q < 3; ++q) { lo[q] = mn(lo[q], bins[k].lo[q]); hi[q] = mx(hi[q], bins[k].hi[q]); }
                     cnt += bins[k].n;
-                    if (cnt == 0 || rn[k + 1] == 0) continue;
+                    if (rn[k + 1] == 0) continue;
                     const double cost = area3(lo, hi) * cnt + ra[k + 1] * rn[k + 1];
                     if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = k; }
                 }
             }
         }
         int32_t mid;
-        if (best_axis < 0) {
-            mid = b + (e - b) / 2;  // all centroids coincide
-        } else {
+        int out = in;  // the array the halves are in
+        Box left, right;
+        if (best_axis >= 0) {
+            // one sweep: every chunk writes its left and right items, in their order, to their final places in the
+            // other array (a chunk's share of the left half is what its own bins counted) and gathers the halves' boxes
             const int a = best_axis;
-            const double sc = scale[a];
-            auto goes_left = [&](const SahItem& it) {
-                int k = (int)((it.c[a] - clo[a]) * sc);
-                if (k >= kBins) k = kBins - 1;
-                return k <= best_split;
-            };
-            if (nt == 1) {
-                // stable split in place: left items close up, right items wait in tmp[b..] (the same range, so
-                // threads working on disjoint ranges do not meet) and are copied back behind them
-                int32_t nl = b, nr = b;
-                for (int32_t i = b; i < e; ++i)
-                    if (goes_left(items[i])) items[nl++] = items[i]; else tmp[nr++] = items[i];
-                std::copy(tmp.get() + b, tmp.get() + nr, items.begin() + nl);
-                mid = nl;
-            } else {
-                // the same split by chunks: count, then every chunk writes its left and right items to their
-                // final places in tmp[b, e), then the range is copied back
-                chunks(b, e, nt, [&](int c, int32_t cb, int32_t ce) {
-                    int32_t n = 0;
-                    for (int32_t i = cb; i < ce; ++i) n += goes_left(items[i]) ? 1 : 0;
-                    ps[c].n_left = n;
-                });
-                int32_t total_left = 0;
-                for (int c = 0; c < nt; ++c) total_left += ps[c].n_left;
-                chunks(b, e, nt, [&](int c, int32_t cb, int32_t ce) {
-                    int32_t nl = b, nr = b + total_left + (cb - b);
-                    for (int k = 0; k < c; ++k) { nl += ps[k].n_left; nr -= ps[k].n_left; }
-                    for (int32_t i = cb; i < ce; ++i)
-                        if (goes_left(items[i])) tmp[nl++] = items[i]; else tmp[nr++] = items[i];
-                });
-                chunks(b, e, nt, [&](int, int32_t cb, int32_t ce) { std::copy(tmp.get() + cb, tmp.get() + ce, items.begin() + cb); });
-                mid = b + total_left;
+            const double sc = scale[a], c0 = clo[a];
+            int32_t total_left = 0;
+            for (int c = 0; c < nt; ++c) {
+                int32_t n = 0;
+                for (int k = 0; k <= best_split; ++k) n += ps[c].bins[a][k].n;
+                ps[c].n_left = n;
+                total_left += n;
             }
-            if (mid == b || mid == e) mid = b + (e - b) / 2;
+            SahItem* dst = buf[in ^ 1].get();
+            chunks(b, e, nt, [&](int c, int32_t cb, int32_t ce) {
+                int32_t nl = b, nr = b + total_left + (cb - b);
+                for (int k = 0; k < c; ++k) { nl += ps[k].n_left; nr -= ps[k].n_left; }
+                Box l, r; l.clear(); r.clear();
+                for (int32_t i = cb; i < ce; ++i) {
+                    const SahItem& it = items[i];
+                    int k = (int)(((it.lo[a] + it.hi[a]) * 0.5 - c0) * sc);
+                    if (k >= kBins) k = kBins - 1;
+                    if (k <= best_split) { l.add(it); dst[nl++] = it; } else { r.add(it); dst[nr++] = it; }
+                }
+                ps[c].left = l; ps[c].right = r;
+            });
+            left.clear(); right.clear();
+            for (int c = 0; c < nt; ++c) { left.add(ps[c].left); right.add(ps[c].right); }
+            mid = b + total_left;
+            out = in ^ 1;
+        }
+        if (best_axis < 0 || mid == b || mid == e) {  // all centroids coincide (or too deep): halve the range where it is
+            mid = b + (e - b) / 2;
+            const SahItem* src = buf[out].get();
+            left.clear(); right.clear();
+            for (int32_t i = b; i < mid; ++i) left.add(src[i]);
+            for (int32_t i = mid; i < e; ++i) right.add(src[i]);
         }
         int32_t l, r;
         if (threads > 1 && mid - b >= kParallelMin && e - mid >= kParallelMin) {
             int tl = (int)(((int64_t)threads * (mid - b) + (e - b) / 2) / (e - b));
             tl = tl < 1 ? 1 : (tl > threads - 1 ? threads - 1 : tl);
-            ThreadGroup left;
-            left.run([&] { l = build(b, mid, depth + 1, tl); });
-            r = build(mid, e, depth + 1, threads - tl);
-            left.join();
+            ThreadGroup fork;
+            fork.run([&] { l = build(b, mid, depth + 1, tl, out, left); });
+            r = build(mid, e, depth + 1, threads - tl, out, right);
+            fork.join();
         } else {  // a short half is not worth a thread: the long one keeps them all
-            l = build(b, mid, depth + 1, mid - b >= e - mid ? threads : 1);
-            r = build(mid, e, depth + 1, mid - b >= e - mid ? 1 : threads);
+            l = build(b, mid, depth + 1, mid - b >= e - mid ? threads : 1, out, left);
+            r = build(mid, e, depth + 1, mid - b >= e - mid ? 1 : threads, out, right);
         }
         b2[me].left = l; b2[me].right = r;
         return me;
@@ -409,86 +446,138 @@ struct SahBuilder {
             slot[bs] = kids[bi]; placed[bi] = true;
         }
     }
-    // slots of every wide node below n; subtrees of at most `grain` shapes are left to `later` (the threads)
-    void widen(int32_t n, int32_t grain, std::vector<int32_t>* later) {
-        if (b2[n].left < 0) return;
-        if (later && b2[n].e - b2[n].b <= grain) { later->push_back(n); return; }
+    // slots of every wide node below n, and span[n] = the HostNodes emit() writes below n (8 per wide node and per
+    // leaf); subtrees of at most `grain` shapes are left to `later` (the threads) and `top` lists the others
+    std::unique_ptr<int32_t[]> span;
+    int32_t widen(int32_t n, int32_t grain, std::vector<int32_t>* later, std::vector<int32_t>* top) {
+        if (b2[n].left < 0) return span[n] = 8;
+        if (later && b2[n].e - b2[n].b <= grain) { later->push_back(n); return 0; }
+        if (top) top->push_back(n);
         choose_slots(n);
+        int32_t sp = 8;
         for (int sl = 0; sl < 8; ++sl)
-            if (wide[n].slot[sl] >= 0) widen(wide[n].slot[sl], grain, later);
+            if (wide[n].slot[sl] >= 0) sp += widen(wide[n].slot[sl], grain, later, top);
+        return span[n] = sp;
     }
     void widen_all(int threads) {
         const int32_t total = n_nodes.load();
         wide.reset(new Wide[(size_t)total]);
+        span.reset(new int32_t[(size_t)total]);
         const int32_t n_items = b2[0].e - b2[0].b;
-        if (threads <= 1 || n_items < kChunkMin) { widen(0, 0, nullptr); return; }
-        std::vector<int32_t> later;
-        widen(0, n_items / (threads * 8) + 1, &later);
+        if (threads <= 1 || n_items < kChunkMin) { widen(0, 0, nullptr, nullptr); return; }
+        std::vector<int32_t> later, top;
+        widen(0, n_items / (threads * 8) + 1, &later, &top);
+        run_jobs(threads, later.size(), [&](size_t i) { widen(later[i], 0, nullptr, nullptr); });
+        for (size_t i = top.size(); i-- > 0;) {  // children come after their parents in `top`
+            const int32_t n = top[i];
+            int32_t sp = 8;
+            for (int sl = 0; sl < 8; ++sl)
+                if (wide[n].slot[sl] >= 0) sp += span[wide[n].slot[sl]];
+            span[n] = sp;
+        }
+    }
+    template <class F>
+    static void run_jobs(int threads, size_t n_jobs, F&& f) {
         std::atomic<size_t> next{0};
         auto work = [&] {
-            for (size_t i = next.fetch_add(1); i < later.size(); i = next.fetch_add(1)) widen(later[i], 0, nullptr);
+            for (size_t i = next.fetch_add(1); i < n_jobs; i = next.fetch_add(1)) f(i);
         };
         ThreadGroup group;
         for (int c = 1; c < threads; ++c) group.run(work);
         work();
         group.join();
     }
-    // wide node for Bvh2 node `n` written into HostNode `at` (sequential: the order fixes the node numbers)
-    void emit(std::vector<HostNode>& out, int32_t n, int32_t at) {
+    // wide node for Bvh2 node `n` written into HostNode `at`, its 8 children from `base` on and their subtrees behind
+    // them in slot order (so a subtree's place follows from the spans before it, and subtrees can be written by
+    // different threads: those of at most `grain` shapes go to `jobs`)
+    struct EmitJob { int32_t n, at, base; };
+    void emit(HostNode* out, int32_t n, int32_t at, int32_t base, int32_t grain, std::vector<EmitJob>* jobs) const {
         const Bvh2& nd = b2[n];
-        for (int a = 0; a < 3; ++a) { out[at].lo[a] = nd.lo[a]; out[at].hi[a] = nd.hi[a]; }
-        out[at].empty = false;
-        out[at].n_shapes = nd.e - nd.b;
-        out[at].shape = -1;
-        const int32_t base = (int32_t)out.size();
-        out[at].child_base = base;
-        out.resize(out.size() + 8);
+        HostNode me;
+        for (int a = 0; a < 3; ++a) { me.lo[a] = nd.lo[a]; me.hi[a] = nd.hi[a]; }
+        me.empty = false;
+        me.n_shapes = nd.e - nd.b;
+        me.shape = -1;
+        me.child_base = base;
+        out[at] = me;
         if (nd.left < 0) {  // leaf: one single-shape child per shape
-            for (int32_t i = nd.b; i < nd.e; ++i) {
-                HostNode& c = out[base + (i - nd.b)];
-                for (int a = 0; a < 3; ++a) { c.lo[a] = items[i].lo[a]; c.hi[a] = items[i].hi[a]; }
-                c.shape = items[i].shape; c.empty = false; c.n_shapes = 1;
+            for (int32_t k = 0; k < 8; ++k) {
+                HostNode c;
+                if (k < nd.e - nd.b) {
+                    const SahItem& it = buf[0][(size_t)(nd.b + k)];
+                    for (int a = 0; a < 3; ++a) { c.lo[a] = it.lo[a]; c.hi[a] = it.hi[a]; }
+                    c.shape = it.shape; c.empty = false; c.n_shapes = 1;
+                } else {
+                    for (int a = 0; a < 3; ++a) c.lo[a] = c.hi[a] = 0;
+                }
+                out[base + k] = c;
             }
             return;
         }
-        for (int sl = 0; sl < 8; ++sl)
-            if (wide[n].slot[sl] >= 0) emit(out, wide[n].slot[sl], base + sl);
+        int32_t next = base + 8;
+        for (int sl = 0; sl < 8; ++sl) {
+            const int32_t c = wide[n].slot[sl];
+            if (c < 0) {
+                HostNode none;
+                for (int a = 0; a < 3; ++a) none.lo[a] = none.hi[a] = 0;
+                out[base + sl] = none;
+                continue;
+            }
+            if (jobs && b2[c].e - b2[c].b <= grain) jobs->push_back({c, base + sl, next});
+            else emit(out, c, base + sl, next, grain, jobs);
+            next += span[c];
+        }
+    }
+    void emit_all(HostNodes& out, int threads) const {
+        out.resize(1 + (size_t)span[0]);
+        const int32_t n_items = b2[0].e - b2[0].b;
+        if (threads <= 1 || n_items < kChunkMin) { emit(out.data(), 0, 0, 1, 0, nullptr); return; }
+        std::vector<EmitJob> jobs;
+        emit(out.data(), 0, 0, 1, n_items / (threads * 8) + 1, &jobs);
+        run_jobs(threads, jobs.size(), [&](size_t i) { emit(out.data(), jobs[i].n, jobs[i].at, jobs[i].base, 0, nullptr); });
     }
 };
 }  // namespace
 
-std::vector<HostNode> build_sah(const rt_shape* shapes, int64_t n, int leaf_size) {
-    std::vector<HostNode> out;
+HostNodes build_sah(const rt_shape* shapes, int64_t n, int leaf_size) {
+    HostNodes out;
     if (n == 0) { out.push_back(HostNode{}); return out; }
     SahBuilder sb;
     sb.leaf_size = leaf_size < 1 ? 1 : (leaf_size > 8 ? 8 : leaf_size);
     // threads building at one time: RTGO_BUILD_THREADS, by default the hardware's but at most 16 (one GPU's
     // share of a node's cores)
-    int threads = (int)std::thread::hardware_concurrency();
-    if (threads > 16) threads = 16;
-    if (const char* ev = std::getenv("RTGO_BUILD_THREADS")) threads = std::atoi(ev);
-    threads = threads < 1 ? 1 : (threads > 32 ? 32 : threads);
-    sb.items.resize((size_t)n);
+    const int threads = builder_threads();
+    const bool timing = std::getenv("RTGO_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[rtgo]   build_sah: %-10s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    sb.buf[0].reset(new SahItem[(size_t)n]);  // not zeroed: the threads that fill the arrays touch their pages first
+    sb.buf[1].reset(new SahItem[(size_t)n]);
     SahBuilder::chunks(0, (int32_t)n, n >= kChunkMin ? threads : 1, [&](int, int32_t cb, int32_t ce) {
         for (int32_t i = cb; i < ce; ++i) {
-            SahItem& it = sb.items[(size_t)i];
+            SahItem& it = sb.buf[0][(size_t)i];
             shape_bounds(shapes[i], it.lo, it.hi);
-            for (int a = 0; a < 3; ++a) it.c[a] = (it.lo[a] + it.hi[a]) * 0.5;
+            for (int a = 0; a < 3; ++a) { it.lo[a] += 0.0; it.hi[a] += 0.0; }  // -0 -> +0 (see SahBuilder::mn)
             it.shape = i;
         }
     });
+    lap("items");
     sb.b2.reset(new Bvh2[2 * (size_t)n]);
-    sb.tmp.reset(new SahItem[(size_t)n]);
-    sb.build(0, (int32_t)n, 0, threads);
-    out.reserve((size_t)n * 3);
-    out.push_back(HostNode{});
+    sb.build(0, (int32_t)n, 0, threads, 0, sb.range_box(0, (int32_t)n, threads));
+    lap("split");
     sb.widen_all(threads);
-    sb.emit(out, 0, 0);
+    lap("widen");
+    sb.emit_all(out, threads);
+    lap("emit");
     return out;
 }
 
 // depth-first, octant order
-static void collect_shapes(const std::vector<HostNode>& nodes, int32_t n, std::vector<int32_t>* out) {
+static void collect_shapes(const HostNodes& nodes, int32_t n, std::vector<int32_t>* out) {
     if (nodes[n].child_base < 0) {
         if (nodes[n].shape >= 0) out->push_back(nodes[n].shape);
         return;
@@ -507,7 +596,7 @@ static void collect_shapes(const std::vector<HostNode>& nodes, int32_t n, std::v
 // A block visit costs the wavefront the same whether 3 or 8 slots are filled, so fuller blocks mean
 // fewer visits per ray; slot ~ octant keeps the k ^ sign visiting order roughly front to back.
 // The order only decides which of two EQUAL-t hits is found first; every box still encloses its shapes.
-static int n_children(const std::vector<HostNode>& nodes, int32_t e) {
+static int n_children(const HostNodes& nodes, int32_t e) {
     int n = 0;
     for (int o = 0; o < 8; ++o) n += nodes[nodes[e].child_base + o].empty ? 0 : 1;
     return n;
@@ -527,15 +616,16 @@ static double box_area(const HostNode& n) {
 struct LeafRule {
     int leaf_size;
     double root_area;
+    bool collapse;  // step 2 of block_slots (off: RTGO_NO_COLLAPSE, an A/B switch for measurements; the oracle mirror has the same one)
 };
-static double max_shape_area(const std::vector<HostNode>& nodes, int32_t n) {
+static double max_shape_area(const HostNodes& nodes, int32_t n) {
     if (nodes[n].child_base < 0) return nodes[n].shape >= 0 ? box_area(nodes[n]) : 0.0;
     double m = 0;
     for (int o = 0; o < 8; ++o)
         if (!nodes[nodes[n].child_base + o].empty) m = std::max(m, max_shape_area(nodes, nodes[n].child_base + o));
     return m;
 }
-static bool is_leaf(const std::vector<HostNode>& nodes, int32_t e, const LeafRule& rule) {
+static bool is_leaf(const HostNodes& nodes, int32_t e, const LeafRule& rule) {
     if (nodes[e].n_shapes > rule.leaf_size) return false;
     if (nodes[e].n_shapes <= 1 || nodes[e].child_base < 0) return true;
     const double a = box_area(nodes[e]);
@@ -543,14 +633,14 @@ static bool is_leaf(const std::vector<HostNode>& nodes, int32_t e, const LeafRul
     return a <= 1.5 * max_shape_area(nodes, e);
 }
 
-static void block_slots(const std::vector<HostNode>& nodes, int32_t x, const LeafRule& rule, int32_t slot[8]) {
+static void block_slots(const HostNodes& nodes, int32_t x, const LeafRule& rule, int32_t slot[8]) {
     int n = 0;
     for (int o = 0; o < 8; ++o) {
         const int32_t c = nodes[x].child_base + o;
         slot[o] = nodes[c].empty ? -1 : skip_chain(nodes, c);
         n += slot[o] >= 0;
     }
-    if (std::getenv("RTGO_NO_COLLAPSE")) return;  // A/B switch for measurements; the oracle mirror has the same one
+    if (!rule.collapse) return;
     double m[3];
     for (int a = 0; a < 3; ++a) m[a] = (nodes[x].lo[a] + nodes[x].hi[a]) * 0.5;
     for (;;) {
@@ -596,10 +686,9 @@ static void block_slots(const std::vector<HostNode>& nodes, int32_t x, const Lea
     }
 }
 
-// The block whose child records are records[first, first + count) (slot order, absent slots omitted), as a QBlock.
-static void append_qblock(FlatTree* out, int64_t first, int count, uint32_t present, uint32_t leaf_mask, uint32_t child_base) {
-    uint32_t w[kQBlockWords] = {};
-    const ChildRecord* rec = out->records.data() + first;
+// The block whose child records are rec[0, count) (slot order, absent slots omitted), as a QBlock written to w.
+static void write_qblock(const ChildRecord* rec, int count, uint32_t present, uint32_t leaf_mask, uint32_t child_base, uint32_t* w) {
+    for (int i = 0; i < kQBlockWords; ++i) w[i] = 0;
     float origin[3], top[3];
     for (int a = 0; a < 3; ++a) {
         origin[a] = rec[0].bmin[a]; top[a] = rec[0].bmax[a];
@@ -643,10 +732,20 @@ static void append_qblock(FlatTree* out, int64_t first, int count, uint32_t pres
             qhi[8 * a + o] = (uint8_t)std::max(0.0, std::min(255.0, hi));
         }
     }
-    out->qblocks.insert(out->qblocks.end(), w, w + kQBlockWords);
 }
 
-bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree* out, const char** err) {
+int builder_threads() {
+    int threads = (int)std::thread::hardware_concurrency();
+    if (threads > 16) threads = 16;
+    if (const char* ev = std::getenv("RTGO_BUILD_THREADS")) threads = std::atoi(ev);
+    return threads < 1 ? 1 : (threads > 32 ? 32 : threads);
+}
+
+// Blocks are numbered breadth-first, and so are their records and the leaves' shapes.  One level at a time: the
+// level's blocks are dealt to the threads in contiguous runs; every thread works its run's blocks out into arrays of
+// its own (slots, leaves, records with run-local indices, the next level's blocks); the runs' lengths are summed up
+// in order; then every thread moves its run to its place in the tree.  The result does not depend on the runs.
+bool flatten_octree(const HostNodes& nodes, int leaf_size, FlatTree* out, const char** err) {
     out->records.clear();
     out->qblocks.clear();
     out->order.clear();
@@ -661,107 +760,151 @@ bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree*
     if (leaf_size < 1) leaf_size = 1;
     if (leaf_size > kMaxLeafSize) leaf_size = kMaxLeafSize;
 
-    auto make_leaf = [&](int32_t e, ChildRecord* r) {
-        const uint32_t first = (uint32_t)out->order.size();
-        collect_shapes(nodes, e, &out->order);
-        r->w0 = (first << 8) | (uint32_t)(out->order.size() - first);
-        r->w1 = kLeafFlag;
-    };
     auto set_box = [&](int32_t e, ChildRecord* r) {
         for (int a = 0; a < 3; ++a) { r->bmin[a] = round_down_f32(nodes[e].lo[a]); r->bmax[a] = round_up_f32(nodes[e].hi[a]); }
     };
-
-    struct Pending { int32_t node; int64_t patch; int32_t level; };  // patch = record whose w0 names this block
-    std::deque<Pending> queue;
-    struct Block { int64_t first; int count; };
-    std::vector<Block> blocks;
-    std::unordered_map<int64_t, int64_t> block_of_first;
     const int32_t root = skip_chain(nodes, 0);
-    const LeafRule rule{leaf_size, box_area(nodes[root])};
+    const LeafRule rule{leaf_size, box_area(nodes[root]), std::getenv("RTGO_NO_COLLAPSE") == nullptr};
     if (is_leaf(nodes, root, rule)) {
         // everything fits one leaf: synthetic root block with that leaf in octant 0
         ChildRecord r;
         set_box(root, &r);
-        make_leaf(root, &r);
-        r.w1 |= 1u;
+        collect_shapes(nodes, root, &out->order);
+        r.w0 = (0u << 8) | (uint32_t)out->order.size();
+        r.w1 = kLeafFlag | 1u;
         out->records.push_back(r);
         out->root_ref = (0u << 8) | 1u;
         out->n_inner = 1; out->depth = 1; out->stack_bound = 8;
-        append_qblock(out, 0, 1, 1u, 1u, 0u);
+        out->qblocks.resize(kQBlockWords);
+        write_qblock(out->records.data(), 1, 1u, 1u, 0u, out->qblocks.data());
         out->block_first.assign(1, 0u);
         out->block_box.assign(8, 0.0f);
         for (int a = 0; a < 3; ++a) { out->block_box[(size_t)a] = r.bmin[a]; out->block_box[(size_t)(4 + a)] = r.bmax[a]; }
         return true;
     }
-    queue.push_back({root, -1, 1});
-    uint32_t n_pushed = 1;  // the i-th node pushed becomes block i (first in, first out)
-    while (!queue.empty()) {
-        const Pending p = queue.front();
-        queue.pop_front();
-        const HostNode& nd = nodes[p.node];
-        const int64_t first = (int64_t)out->records.size();
-        int32_t slot[8];
-        block_slots(nodes, p.node, rule, slot);
-        uint32_t present = 0, leaf_mask = 0, child_base = 0;
-        for (int o = 0; o < 8; ++o) {
-            const int32_t e = slot[o];
-            if (e < 0) continue;
-            present |= 1u << o;
-            ChildRecord r;
-            set_box(e, &r);
-            if (is_leaf(nodes, e, rule)) {
-                make_leaf(e, &r);
-                leaf_mask |= 1u << o;
-            } else {
-                r.w0 = 0; r.w1 = 0;
-                if ((present & ~leaf_mask) == (1u << o)) child_base = n_pushed;  // first inner child of this block
-                ++n_pushed;
-                queue.push_back({e, (int64_t)out->records.size(), p.level + 1});
+
+    struct Pending { int32_t node; int64_t patch; };  // patch = record whose w0 names this block
+    struct BlockTmp { int32_t first; uint8_t count, present, leaf_mask, inner; int32_t inner_before; };
+    struct Run {  // of a level's blocks
+        size_t b, e;
+        std::vector<ChildRecord> recs;
+        std::vector<int32_t> order;
+        std::vector<Pending> next;
+        std::vector<BlockTmp> blocks;
+        int64_t rec_base, order_base, pushed_base;
+    };
+    struct BlockInfo { uint32_t child_base; int32_t inner; };
+    std::vector<BlockInfo> info;  // by block
+    const int threads = builder_threads();
+    std::vector<Pending> level{{root, -1}};
+    int depth = 0;
+    while (!level.empty()) {
+        ++depth;
+        const size_t n_blocks_before = info.size();
+        const int nt = (int)std::min<size_t>((size_t)threads, level.size() / 256 + 1);
+        std::vector<Run> runs((size_t)nt);
+        for (int c = 0; c < nt; ++c) { runs[(size_t)c].b = level.size() * (size_t)c / (size_t)nt; runs[(size_t)c].e = level.size() * (size_t)(c + 1) / (size_t)nt; }
+        auto on_runs = [&](auto&& f) {
+            if (nt == 1) { f(runs[0]); return; }
+            ThreadGroup group;
+            for (int c = 1; c < nt; ++c) group.run([&f, &runs, c] { f(runs[(size_t)c]); });
+            f(runs[0]);
+            group.join();
+        };
+        on_runs([&](Run& run) {
+            int32_t inner_before = 0;
+            for (size_t i = run.b; i < run.e; ++i) {
+                int32_t slot[8];
+                block_slots(nodes, level[i].node, rule, slot);
+                BlockTmp bt{(int32_t)run.recs.size(), 0, 0, 0, 0, inner_before};
+                for (int o = 0; o < 8; ++o) {
+                    const int32_t e = slot[o];
+                    if (e < 0) continue;
+                    bt.present |= (uint8_t)(1u << o);
+                    ChildRecord r;
+                    set_box(e, &r);
+                    if (is_leaf(nodes, e, rule)) {
+                        const uint32_t first = (uint32_t)run.order.size();
+                        collect_shapes(nodes, e, &run.order);
+                        r.w0 = (first << 8) | (uint32_t)(run.order.size() - first);
+                        r.w1 = kLeafFlag;
+                        bt.leaf_mask |= (uint8_t)(1u << o);
+                    } else {
+                        r.w0 = 0; r.w1 = 0;
+                        run.next.push_back({e, (int64_t)run.recs.size()});
+                        ++bt.inner;
+                    }
+                    run.recs.push_back(r);
+                }
+                bt.count = (uint8_t)(run.recs.size() - (size_t)bt.first);
+                inner_before += bt.inner;
+                run.blocks.push_back(bt);
             }
-            out->records.push_back(r);
+        });
+        int64_t n_rec = (int64_t)out->records.size(), n_order = (int64_t)out->order.size();
+        int64_t n_pushed = (int64_t)(n_blocks_before + level.size());  // the i-th block found is block i (root = 0)
+        size_t n_next = 0;
+        for (Run& run : runs) {
+            run.rec_base = n_rec; run.order_base = n_order; run.pushed_base = n_pushed;
+            n_rec += (int64_t)run.recs.size(); n_order += (int64_t)run.order.size(); n_pushed += (int64_t)run.next.size();
+            n_next += run.next.size();
         }
-        append_qblock(out, first, (int)(out->records.size() - (size_t)first), present, leaf_mask, child_base);
-        (void)nd;
-        for (size_t k = (size_t)first; k < out->records.size(); ++k) out->records[k].w1 |= leaf_mask;
-        if ((int64_t)out->records.size() > kMaxChildRecords || (int64_t)out->order.size() >= kMaxChildRecords) {
+        if (n_rec > kMaxChildRecords || n_order >= kMaxChildRecords) {
             *err = "scene too large: the flattened octree exceeds 2^24 child records";
             return false;
         }
-        const uint32_t ref = ((uint32_t)first << 8) | present;
-        block_of_first[first] = (int64_t)blocks.size();
-        blocks.push_back({first, (int)(out->records.size() - (size_t)first)});
-        if (p.patch < 0) out->root_ref = ref; else out->records[(size_t)p.patch].w0 = ref;
-        out->n_inner++;
-        if (p.level > out->depth) out->depth = p.level;
+        out->records.resize((size_t)n_rec);
+        out->order.resize((size_t)n_order);
+        info.resize(n_blocks_before + level.size());
+        out->qblocks.resize(info.size() * kQBlockWords);
+        out->block_first.resize(info.size());
+        out->block_box.resize(info.size() * 8);
+        std::vector<Pending> next(n_next);
+        on_runs([&](Run& run) {
+            std::copy(run.order.begin(), run.order.end(), out->order.begin() + run.order_base);
+            ChildRecord* recs = out->records.data() + run.rec_base;
+            for (size_t k = 0; k < run.recs.size(); ++k) {
+                recs[k] = run.recs[k];
+                if (recs[k].w1 & kLeafFlag) recs[k].w0 += (uint32_t)run.order_base << 8;
+            }
+            size_t at = (size_t)(run.pushed_base - (int64_t)(n_blocks_before + level.size()));
+            for (const Pending& p : run.next) next[at++] = {p.node, run.rec_base + p.patch};
+            for (size_t j = 0; j < run.blocks.size(); ++j) {
+                const BlockTmp& bt = run.blocks[j];
+                const size_t block = n_blocks_before + run.b + j;
+                ChildRecord* rec = recs + bt.first;
+                for (int k = 0; k < bt.count; ++k) rec[k].w1 |= bt.leaf_mask;
+                const uint32_t child_base = bt.inner ? (uint32_t)(run.pushed_base + bt.inner_before) : 0u;  // its first inner child's block
+                write_qblock(rec, bt.count, bt.present, bt.leaf_mask, child_base, out->qblocks.data() + block * kQBlockWords);
+                const uint32_t first = (uint32_t)(run.rec_base + bt.first);
+                const uint32_t ref = (first << 8) | bt.present;
+                const int64_t patch = level[run.b + j].patch;  // a record of the level above: final, and named by this block alone
+                if (patch < 0) out->root_ref = ref; else out->records[(size_t)patch].w0 = ref;
+                out->block_first[block] = first;
+                float* bb = out->block_box.data() + block * 8;
+                bb[3] = bb[7] = 0.0f;
+                for (int a = 0; a < 3; ++a) {
+                    bb[a] = rec[0].bmin[a]; bb[4 + a] = rec[0].bmax[a];
+                    for (int k = 1; k < bt.count; ++k) { bb[a] = std::min(bb[a], rec[k].bmin[a]); bb[4 + a] = std::max(bb[4 + a], rec[k].bmax[a]); }
+                }
+                info[block] = {child_base, bt.inner};
+            }
+        });
+        level.swap(next);
     }
-    out->block_first.assign(blocks.size(), 0u);
-    out->block_box.assign(blocks.size() * 8, 0.0f);
-    for (size_t i = 0; i < blocks.size(); ++i) {
-        out->block_first[i] = (uint32_t)blocks[i].first;
-        float* bb = out->block_box.data() + i * 8;
-        const ChildRecord* rec = out->records.data() + blocks[i].first;
-        for (int a = 0; a < 3; ++a) {
-            bb[a] = rec[0].bmin[a]; bb[4 + a] = rec[0].bmax[a];
-            for (int k = 1; k < blocks[i].count; ++k) { bb[a] = std::min(bb[a], rec[k].bmin[a]); bb[4 + a] = std::max(bb[4 + a], rec[k].bmax[a]); }
-        }
-    }
+    out->n_inner = (int64_t)info.size();
+    out->depth = depth;
     // Worst-case traversal stack: entering a block pushes at most (inner children - 1) entries and descends
     // into one inner child, so the deepest stack below block b is need(b) = (inner(b) - 1) + max over its
-    // inner children of need(child).  Blocks are in breadth-first order: children come after their parent.
+    // inner children of need(child).  Blocks are in breadth-first order: children come after their parent, and a
+    // block's inner children are consecutive blocks.
     {
-        std::vector<int32_t> need(blocks.size(), 0);
-        for (int64_t i = (int64_t)blocks.size() - 1; i >= 0; --i) {
-            const int64_t first = blocks[(size_t)i].first;
-            const int n = blocks[(size_t)i].count;
-            int inner = 0, deepest = 0;
-            for (int k = 0; k < n; ++k) {
-                const ChildRecord& r = out->records[(size_t)(first + k)];
-                if (r.w1 & kLeafFlag) continue;
-                ++inner;
-                const auto it = block_of_first.find((int64_t)(r.w0 >> 8));
-                if (it != block_of_first.end()) deepest = std::max(deepest, need[(size_t)it->second]);
-            }
-            need[(size_t)i] = (inner > 0 ? inner - 1 : 0) + deepest;
+        std::vector<int32_t> need(info.size(), 0);
+        for (int64_t i = (int64_t)info.size() - 1; i >= 0; --i) {
+            const BlockInfo& bi = info[(size_t)i];
+            int deepest = 0;
+            for (int k = 0; k < bi.inner; ++k) deepest = std::max(deepest, need[(size_t)bi.child_base + (size_t)k]);
+            need[(size_t)i] = (bi.inner > 0 ? bi.inner - 1 : 0) + deepest;
         }
         out->stack_bound = (need.empty() ? 0 : need[0]) + 1;
     }

@@ -26,6 +26,7 @@
 #pragma once
 #include <cstdint>
 #include <exception>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <utility>
@@ -92,6 +93,19 @@ struct HostNode {
     int32_t n_shapes = 0; // after refit(): shapes in the subtree
 };
 
+// std::vector<HostNode> whose resize(n) leaves the new elements unwritten (HostNode is trivially copyable and
+// destructible; whoever resizes writes every new element in full): the SAH builder's threads fill the nodes of a
+// 10^6-shape tree themselves, and with that touch the pages of their own parts first
+template <class T>
+struct DefaultInit : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInit<U>; };
+    DefaultInit() = default;
+    template <class U> DefaultInit(const DefaultInit<U>&) {}
+    template <class U> void construct(U*) {}
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+using HostNodes = std::vector<HostNode, DefaultInit<HostNode>>;
+
 struct ChildRecord {  // 32 bytes, read by the kernels as two float4
     float bmin[3];
     float bmax[3];
@@ -111,7 +125,7 @@ struct FlatTree {
 };
 
 // shapes: desc->shapes[0..n). Returns nodes[0] = root.
-std::vector<HostNode> build_octree(const rt_shape* shapes, int64_t n);
+HostNodes build_octree(const rt_shape* shapes, int64_t n);
 // The default tree ("faster builder"): a binned-SAH BVH in the same 8-slot node form, so
 // that flatten_octree() and the traversal are shared with the reference's octree (RTGO_TREE=octree).
 //   split(range): boxes and centroid bounds (centroid = centre of the shape's box); at most leaf_size
@@ -128,8 +142,10 @@ std::vector<HostNode> build_octree(const rt_shape* shapes, int64_t n);
 //     halves by their lengths; min, max and counts merge exactly, so the tree does not depend on it.
 // Any tree whose boxes enclose their shapes gives the same hits; only the order in which equal-t hits
 // are found depends on it, which is why the oracle's fp32 mode restates this builder too.
-std::vector<HostNode> build_sah(const rt_shape* shapes, int64_t n, int leaf_size);
+HostNodes build_sah(const rt_shape* shapes, int64_t n, int leaf_size);
+// Threads the builders and the flattener use: RTGO_BUILD_THREADS, by default the hardware's but at most 16.
+int builder_threads();
 // Returns false (and sets *err) if the tree exceeds kMaxChildRecords.
-bool flatten_octree(const std::vector<HostNode>& nodes, int leaf_size, FlatTree* out, const char** err);
+bool flatten_octree(const HostNodes& nodes, int leaf_size, FlatTree* out, const char** err);
 
 }  // namespace rtgo

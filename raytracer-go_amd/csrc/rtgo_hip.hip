@@ -21,6 +21,7 @@
 #include <thread>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <mutex>
 #include <new>
 #include <stdexcept>
@@ -986,6 +987,35 @@ extern "C" {
 
 const char* rt_last_error(void) { return g_err.c_str(); }
 
+// The HIP runtime sets up its copy path on the first hipMemcpy of the process (about 150 ms on an MI355X box,
+// RTGO_TIMING=1; a first hipMalloc alone does not trigger it).  The first rt_init of a device starts a thread that
+// pays that with a small copy and memset while the caller goes on (flattening its scene, then the tree build in
+// rt_scene_create, which waits for the thread before its first upload): one-shot frame 0.83 s -> 0.71 s when the thread
+// started with the tree build, and less again when the caller calls rt_init before it prepares the scene.
+static std::mutex g_warm_mutex;
+static std::shared_future<void> g_warm[kMaxDevices];
+static void start_warm_up(int device) {
+    if (device < 0 || device >= kMaxDevices) return;
+    std::lock_guard<std::mutex> g(g_warm_mutex);
+    if (g_warm[device].valid()) return;
+    g_warm[device] = std::async(std::launch::async, [device] {
+        void* p = nullptr;
+        std::vector<char> host((size_t)4 << 20, 1);
+        if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, host.size()) != hipSuccess) return;
+        (void)hipMemcpy(p, host.data(), host.size(), hipMemcpyHostToDevice);
+        (void)hipMemset(p, 0, host.size());
+        (void)hipFree(p);
+    }).share();
+}
+static void wait_warm_up(int device) {
+    std::shared_future<void> f;
+    {
+        std::lock_guard<std::mutex> g(g_warm_mutex);
+        if (device >= 0 && device < kMaxDevices) f = g_warm[device];
+    }
+    if (f.valid()) f.wait();
+}
+
 int rt_init(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -1004,6 +1034,7 @@ int rt_init(int device) {
             g_scratch_ptr[device] = ptr;
         }
     }
+    start_warm_up(device);
     return RT_OK;
 }
 
@@ -1041,10 +1072,10 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     }
     for (int64_t i = 0; i < desc->n_lights; ++i)
         if (desc->lights[i].kind < RT_LIGHT_AMBIENT || desc->lights[i].kind > RT_LIGHT_SPOT) return fail(RT_ERR_INVALID, "unknown light kind");
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = rt_init(device);
     if (rc != RT_OK) return rc;
 
-    const auto t0 = std::chrono::steady_clock::now();
     // RTGO_TIMING=1: the phases of scene creation on stderr (host tree build, flattening, tables, uploads)
     const bool timing = std::getenv("RTGO_TIMING") != nullptr;
     auto lap = [&, last = t0](const char* what) mutable {
@@ -1053,21 +1084,32 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
         std::fprintf(stderr, "[rtgo] scene create: %-10s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
         last = now;
     };
-    // The HIP runtime sets up its copy path on the first hipMemcpy of the process (about 150 ms on an MI355X box,
-    // RTGO_TIMING=1; a first hipMalloc alone does not trigger it): a thread pays that with a small copy and memset
-    // while this one builds the tree, and is joined before the first upload (one-shot frame 0.83 s -> 0.71 s).
-    struct Warm {
-        std::thread t;
-        void join() { if (t.joinable()) t.join(); }
-        ~Warm() { join(); }
-    } warm;
-    warm.t = std::thread([device] {
-        void* p = nullptr;
-        std::vector<char> host((size_t)4 << 20, 1);
-        if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, host.size()) != hipSuccess) return;
-        (void)hipMemcpy(p, host.data(), host.size(), hipMemcpyHostToDevice);
-        (void)hipMemset(p, 0, host.size());
-        (void)hipFree(p);
+    lap("rt_init");
+    rt_scene* s = new rt_scene();
+    struct Guard {  // an exception (std::bad_alloc in a table, std::system_error from a thread) must not leak the device buffers
+        rt_scene* s;
+        ~Guard() { if (s) rt_scene_destroy(s); }
+    } guard{s};
+    s->device = device;
+    // Declared after the guard: whichever way this function is left, the thread has ended (a std::async future waits
+    // in its destructor) before the guard releases the scene.
+    std::future<std::pair<hipError_t, const char*>> lane_setup = std::async(std::launch::async, [s, device]() -> std::pair<hipError_t, const char*> {
+#define HIP_TRY_L(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return {e_, #expr}; } while (0)
+        HIP_TRY_L(hipSetDevice(device));
+        for (int l = 0; l < kLanes; ++l) {
+            Lane& ln = s->lanes[l];
+            ln.ev_ok = true;  // from here on rt_scene_destroy() releases whatever of the lane exists
+            ln.h_counter_words = (size_t)(3 * kStaticDepth + 8);
+            HIP_TRY_L(hipHostMalloc((void**)&ln.h_counters, kSnapshots * ln.h_counter_words * sizeof(uint32_t)));
+            for (auto& e : ln.ev_snap) HIP_TRY_L(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto& e : ln.ev_frame) HIP_TRY_L(hipEventCreate(&e));
+            HIP_TRY_L(hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
+            if (l > 0) HIP_TRY_L(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        }
+        HIP_TRY_L(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        for (auto& e : s->ev_wall) HIP_TRY_L(hipEventCreate(&e));
+        return {hipSuccess, ""};
+#undef HIP_TRY_L
     });
     FlatTree flat;
     {
@@ -1078,7 +1120,7 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
         const bool octree = tree && std::strcmp(tree, "octree") == 0;
         const int leaf_size = ls ? std::atoi(ls) : (octree ? kDefaultLeafSize : kDefaultLeafSizeSah);
         // default: binned-SAH tree (octree.hpp); RTGO_TREE=octree builds the reference's insertion octree
-        const std::vector<HostNode> nodes = octree
+        const HostNodes nodes = octree
                                                 ? build_octree(desc->shapes, desc->n_shapes)
                                                 : build_sah(desc->shapes, desc->n_shapes, leaf_size);
         lap("tree");
@@ -1089,12 +1131,16 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     // shapes -> 3 float4 each, narrowed to fp32 (round to nearest), stored in leaf order
     // tprims: the same records for the intersection tests, with the triangle's edges e1 = B - A, e2 = C - A (fp32
     // differences of the fp32 vertices, exactly what the tests would compute) in place of B and C
-    std::vector<float> prims((size_t)desc->n_shapes * 12 + 12, 0.0f), tprims((size_t)desc->n_shapes * 12 + 12, 0.0f);
+    // (not zeroed first: the threads write all 12 words of every record, and the pages are theirs to touch)
+    const size_t prim_words = (size_t)desc->n_shapes * 12 + 12;
+    std::unique_ptr<float[]> prims(new float[prim_words]), tprims(new float[prim_words]);
+    for (size_t k = prim_words - 12; k < prim_words; ++k) prims[k] = tprims[k] = 0.0f;  // the padding record
     host_chunks(desc->n_shapes, [&](int64_t q0, int64_t q1) {
         for (int64_t q = q0; q < q1; ++q) {
             const rt_shape& s = desc->shapes[flat.order[(size_t)q]];
-            float* p = prims.data() + (size_t)q * 12;
-            float* t = tprims.data() + (size_t)q * 12;
+            float* p = prims.get() + (size_t)q * 12;
+            float* t = tprims.get() + (size_t)q * 12;
+            for (int k = 0; k < 12; ++k) p[k] = t[k] = 0.0f;
             uint32_t bits = (uint32_t)s.material << 2;
             if (s.kind == RT_SHAPE_TRIANGLE) {
                 bits |= kPrimTriangle | (s.single_sided ? kPrimSingleSided : 0u);
@@ -1123,14 +1169,8 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     }
 
     lap("tables");
-    warm.join();
+    wait_warm_up(device);  // started by rt_init
     lap("hip warm");
-    rt_scene* s = new rt_scene();
-    struct Guard {  // an exception (std::bad_alloc in a table, std::system_error from a thread) must not leak the device buffers
-        rt_scene* s;
-        ~Guard() { if (s) rt_scene_destroy(s); }
-    } guard{s};
-    s->device = device;
     s->from = desc->camera_look_from; s->at = desc->camera_look_at; s->up = desc->camera_up;
     s->aperture = desc->camera_aperture; s->fov = desc->camera_fov_deg;
     auto bail = [&](int code) { return code; };  // the guard releases the scene
@@ -1188,10 +1228,10 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     if (!flat.records.empty()) HIP_TRY_S(hipMemcpy(s->d_recs, flat.records.data(), flat.records.size() * sizeof(ChildRecord), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_qblocks, flat.qblocks.size() * sizeof(uint32_t)));
     HIP_TRY_S(hipMemcpy(s->d_qblocks, flat.qblocks.data(), flat.qblocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY_S(hipMalloc(&s->d_prims, prims.size() * sizeof(float)));
-    HIP_TRY_S(hipMemcpy(s->d_prims, prims.data(), prims.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY_S(hipMalloc(&s->d_tprims, tprims.size() * sizeof(float)));
-    HIP_TRY_S(hipMemcpy(s->d_tprims, tprims.data(), tprims.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_prims, prim_words * sizeof(float)));
+    HIP_TRY_S(hipMemcpy(s->d_prims, prims.get(), prim_words * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_tprims, prim_words * sizeof(float)));
+    HIP_TRY_S(hipMemcpy(s->d_tprims, tprims.get(), prim_words * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_prim_ids, (flat.order.size() + 1) * sizeof(int32_t)));
     if (!flat.order.empty()) HIP_TRY_S(hipMemcpy(s->d_prim_ids, flat.order.data(), flat.order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_block_first, flat.block_first.size() * sizeof(uint32_t)));
@@ -1214,23 +1254,15 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     s->d.materials = (const DMaterial*)s->d_mats; s->d.textures = (const DTexture*)s->d_texs;
     s->d.lights = (const DLight*)s->d_lights;
     s->d.n_lights = (int)desc->n_lights; s->d.n_pos_lights = n_pos; s->d.root_ref = flat.root_ref;
-    for (int l = 0; l < kLanes; ++l) {
-        Lane& ln = s->lanes[l];
-        ln.ev_ok = true;  // from here on rt_scene_destroy() releases whatever of the lane exists
-        ln.h_counter_words = (size_t)(3 * kStaticDepth + 8);
-        HIP_TRY_S(hipHostMalloc((void**)&ln.h_counters, kSnapshots * ln.h_counter_words * sizeof(uint32_t)));
-        for (auto& e : ln.ev_snap) HIP_TRY_S(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto& e : ln.ev_frame) HIP_TRY_S(hipEventCreate(&e));
-        HIP_TRY_S(hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
-        if (l > 0) HIP_TRY_S(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+    {  // the lanes' events, streams and pinned counters: made by a thread of their own since the tree build began
+        const std::pair<hipError_t, const char*> made = lane_setup.get();
+        if (made.first != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string(made.second) + ": " + hipGetErrorString(made.first)));
     }
-    HIP_TRY_S(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-    for (auto& e : s->ev_wall) HIP_TRY_S(hipEventCreate(&e));
 
     s->info.n_shapes = desc->n_shapes; s->info.n_inner_nodes = flat.n_inner;
     s->info.n_child_records = (int64_t)flat.records.size();
     s->info.tree_depth = flat.depth; s->info.stack_bound = flat.stack_bound;
-    s->info.device_bytes = (int64_t)(rec_bytes + flat.qblocks.size() * 4 + prims.size() * 4 + tprims.size() * 4 + mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
+    s->info.device_bytes = (int64_t)(rec_bytes + flat.qblocks.size() * 4 + prim_words * 4 + prim_words * 4 + mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
                                      lights.size() * sizeof(DLight)) + tex_bytes;  // + the spill region, see ensure_overflow()
     lap("events");
     s->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

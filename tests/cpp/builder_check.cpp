@@ -118,7 +118,7 @@ static void walk_q(const FlatTree& t, uint32_t ref, uint32_t blk, size_t* visite
 
 static void check_scene(const char* name, const std::vector<rt_shape>& shapes, int leaf_size) {
     for (int kind = 0; kind < 2; ++kind) {
-        const std::vector<HostNode> nodes = kind == 0 ? build_sah(shapes.data(), (int64_t)shapes.size(), leaf_size)
+        const HostNodes nodes = kind == 0 ? build_sah(shapes.data(), (int64_t)shapes.size(), leaf_size)
                                                       : build_octree(shapes.data(), (int64_t)shapes.size());
         FlatTree t;
         const char* err = nullptr;
