@@ -13,6 +13,7 @@
 #include <atomic>
 #include <memory>
 #include <thread>
+#include <condition_variable>
 #include <chrono>
 #include <cstdio>
 
@@ -195,7 +196,6 @@ double area3(const double lo[3], const double hi[3]) {
     return 2.0 * ((dx * dy + dy * dz) + dz * dx);
 }
 constexpr int kMaxSahDepth = 48;
-constexpr int32_t kParallelMin = 16384;  // ranges at least this long may be split off to a thread of their own
 constexpr int32_t kChunkMin = 131072;    // ranges at least this long are swept by several threads
 struct SahBuilder {
     // min / max of finite numbers as one instruction each (std::fmin's NaN rule costs three).  The items' coordinates
@@ -295,7 +295,7 @@ struct SahBuilder {
         int best_axis = -1, best_split = 0;
         double best_cost = DBL_MAX;
         if (any) {
-            chunks(b, e, nt, [&](int c, int32_t cb, int32_t ce) {  // the three axes' bins in one sweep
+            pool_chunks(b, e, nt, [&](int c, int32_t cb, int32_t ce) {  // the three axes' bins in one sweep
                 Pass& p = ps[c];
                 for (int a = 0; a < 3; ++a)
                     for (auto& bn : p.bins[a]) { bn.n = 0; for (int k = 0; k < 3; ++k) { bn.lo[k] = DBL_MAX; bn.hi[k] = -DBL_MAX; } }
@@ -362,7 +362,7 @@ struct SahBuilder {
                 total_left += n;
             }
             SahItem* dst = buf[in ^ 1].get();
-            chunks(b, e, nt, [&](int c, int32_t cb, int32_t ce) {
+            pool_chunks(b, e, nt, [&](int c, int32_t cb, int32_t ce) {
                 int32_t nl = b, nr = b + total_left + (cb - b);
                 for (int k = 0; k < c; ++k) { nl += ps[k].n_left; nr -= ps[k].n_left; }
                 Box l, r; l.clear(); r.clear();
@@ -386,20 +386,143 @@ struct SahBuilder {
             for (int32_t i = b; i < mid; ++i) left.add(src[i]);
             for (int32_t i = mid; i < e; ++i) right.add(src[i]);
         }
-        int32_t l, r;
-        if (threads > 1 && mid - b >= kParallelMin && e - mid >= kParallelMin) {
-            int tl = (int)(((int64_t)threads * (mid - b) + (e - b) / 2) / (e - b));
-            tl = tl < 1 ? 1 : (tl > threads - 1 ? threads - 1 : tl);
-            ThreadGroup fork;
-            fork.run([&] { l = build(b, mid, depth + 1, tl, out, left); });
-            r = build(mid, e, depth + 1, threads - tl, out, right);
-            fork.join();
-        } else {  // a short half is not worth a thread: the long one keeps them all
-            l = build(b, mid, depth + 1, mid - b >= e - mid ? threads : 1, out, left);
-            r = build(mid, e, depth + 1, mid - b >= e - mid ? 1 : threads, out, right);
-        }
-        b2[me].left = l; b2[me].right = r;
+        // The halves.  On the thread that builds the top of the tree (threads > 1: ranges long enough for chunked sweeps)
+        // a shorter half goes to the task list; on a worker (threads == 1) the right half does when both are worth a task.
+        const bool queue_left = pool_on && threads > 1 && mid - b < kChunkMin;
+        const bool queue_right = pool_on && (threads > 1 ? e - mid < kChunkMin : (mid - b >= grain && e - mid >= grain));
+        if (queue_right) push({mid, e, depth + 1, out, right, &b2[me].right});
+        if (queue_left) push({b, mid, depth + 1, out, left, &b2[me].left});
+        if (!queue_left) { const int32_t l = build(b, mid, depth + 1, threads, out, left); b2[me].left = l; }
+        if (!queue_right) { const int32_t r = build(mid, e, depth + 1, threads, out, right); b2[me].right = r; }
         return me;
+    }
+    // ---- tasks: subtrees that any thread may build (a split into two halves says little about how long each takes
+    // to build, so the threads are not shared out over the halves: they take the longest range waiting) ----
+    struct Task { int32_t b, e; int depth, in; Box bx; int32_t* link; };  // link: where the subtree's node number goes
+    std::mutex qm;
+    std::condition_variable qcv;
+    std::vector<Task> tasks;
+    int64_t outstanding = 0;  // tasks pushed and not finished (a task pushes its own before it finishes)
+    bool pool_on = false, failed = false;
+    std::exception_ptr failure;
+    int32_t grain = INT32_MAX;  // ranges shorter than this are not worth a task
+    void push(const Task& t) {
+        {
+            std::lock_guard<std::mutex> g(qm);
+            tasks.push_back(t);
+            ++outstanding;
+        }
+        qcv.notify_one();
+    }
+    // A chunk of a sweep over a long range: taken before any subtree, by whichever thread is free, and by the thread
+    // that asked for the sweep itself as long as chunks of it are waiting (so a sweep never waits for a busy thread
+    // to start a chunk, only for the chunks that are running to end).
+    struct ChunkJob { void (*run)(void*, int, int32_t, int32_t); void* ctx; int c; int32_t cb, ce; std::atomic<int>* left; };
+    std::vector<ChunkJob> chunk_jobs;
+    void run_chunk(const ChunkJob& j) {
+        try {
+            j.run(j.ctx, j.c, j.cb, j.ce);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(qm);
+            if (!failed) { failed = true; failure = std::current_exception(); }
+        }
+        j.left->fetch_sub(1, std::memory_order_acq_rel);
+    }
+    template <class F>
+    void pool_chunks(int32_t b, int32_t e, int nt, F&& f) {
+        if (nt <= 1) { f(0, b, e); return; }
+        if (!pool_on) { chunks(b, e, nt, f); return; }
+        using Fn = typename std::remove_reference<F>::type;
+        std::atomic<int> left{nt - 1};
+        const int64_t len = e - b;
+        {
+            std::lock_guard<std::mutex> g(qm);
+            for (int c = 1; c < nt; ++c)
+                chunk_jobs.push_back({[](void* ctx, int c_, int32_t cb, int32_t ce) { (*static_cast<Fn*>(ctx))(c_, cb, ce); }, (void*)&f, c,
+                                      b + (int32_t)(len * c / nt), b + (int32_t)(len * (c + 1) / nt), &left});
+        }
+        qcv.notify_all();
+        f(0, b, b + (int32_t)(len / nt));
+        for (;;) {
+            ChunkJob j;
+            {
+                std::lock_guard<std::mutex> g(qm);
+                if (chunk_jobs.empty()) break;
+                j = chunk_jobs.back();
+                chunk_jobs.pop_back();
+            }
+            run_chunk(j);
+        }
+        while (left.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    }
+    void work() {
+        for (;;) {
+            Task t;
+            ChunkJob j;
+            bool is_chunk = false;
+            {
+                std::unique_lock<std::mutex> lk(qm);
+                qcv.wait(lk, [&] { return failed || !chunk_jobs.empty() || !tasks.empty() || (done_top && outstanding == 0); });
+                if (!chunk_jobs.empty()) {
+                    j = chunk_jobs.back();
+                    chunk_jobs.pop_back();
+                    is_chunk = true;
+                } else {
+                    if (failed || tasks.empty()) return;
+                    size_t pick = 0;
+                    for (size_t i = 1; i < tasks.size(); ++i)
+                        if (tasks[i].e - tasks[i].b > tasks[pick].e - tasks[pick].b) pick = i;
+                    t = tasks[pick];
+                    tasks[pick] = tasks.back();
+                    tasks.pop_back();
+                }
+            }
+            if (is_chunk) { run_chunk(j); continue; }
+            try {
+                *t.link = build(t.b, t.e, t.depth, 1, t.in, t.bx);
+            } catch (...) {
+                std::lock_guard<std::mutex> g(qm);
+                if (!failed) { failed = true; failure = std::current_exception(); }
+            }
+            bool wake;
+            {
+                std::lock_guard<std::mutex> g(qm);
+                --outstanding;
+                wake = failed || (done_top && outstanding == 0);
+            }
+            if (wake) qcv.notify_all();
+        }
+    }
+    bool done_top = false;  // the top of the tree is built: no task comes from there any more
+    int32_t build_all(int32_t n, int threads) {
+        const Box all = range_box(0, n, threads);
+        if (threads <= 1) return build(0, n, 0, 1, 0, all);
+        pool_on = true;
+        grain = std::max<int32_t>(1024, n / (threads * 8));
+        const auto t_begin = std::chrono::steady_clock::now();
+        int32_t root = -1;
+        {
+            ThreadGroup group;
+            for (int c = 1; c < threads; ++c) group.run([this] { work(); });
+            try {
+                root = build(0, n, 0, threads, 0, all);
+            } catch (...) {
+                std::lock_guard<std::mutex> g(qm);
+                if (!failed) { failed = true; failure = std::current_exception(); }
+            }
+            {
+                std::lock_guard<std::mutex> g(qm);
+                done_top = true;
+            }
+            qcv.notify_all();
+            if (std::getenv("RTGO_TIMING"))
+                std::fprintf(stderr, "[rtgo]   build_sah: top of the tree done %.2f ms after the split began\n",
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+            work();
+            group.join();
+        }
+        if (failed) std::rethrow_exception(failure);
+        return root;
     }
     // ---- widening: which Bvh2 nodes become the up-to-8 children of a wide node, and in which slots ----
     struct Wide { int32_t slot[8]; };
@@ -567,7 +690,7 @@ HostNodes build_sah(const rt_shape* shapes, int64_t n, int leaf_size) {
     });
     lap("items");
     sb.b2.reset(new Bvh2[2 * (size_t)n]);
-    sb.build(0, (int32_t)n, 0, threads, 0, sb.range_box(0, (int32_t)n, threads));
+    sb.build_all((int32_t)n, threads);
     lap("split");
     sb.widen_all(threads);
     lap("widen");

@@ -137,9 +137,12 @@ HostNodes build_octree(const rt_shape* shapes, int64_t n);
 //     with the largest area (first on ties) is replaced by its left child, its right child appended;
 //     children take slots by the greedy octant matching of block_slots.  A leaf's shapes become
 //     single-shape children in slots 0.. in range order.
-//   Threads (RTGO_BUILD_THREADS, default min(hardware, 16)): ranges of >= 131072 shapes are swept in
-//     chunks by all the threads their subtree may use, and a split shares those threads out over its two
-//     halves by their lengths; min, max and counts merge exactly, so the tree does not depend on it.
+//   Threads (RTGO_BUILD_THREADS, default min(hardware, 16)): one thread builds the top of the tree, whose ranges
+//     (>= 131072 shapes) are swept in chunks by whichever threads are free; every shorter range is a task that the
+//     threads take longest first, and a task hands its right half on as a new task while both halves are worth one.
+//     A range is split by one sweep from one of two arrays into the other, which also gathers its halves' boxes.
+//     min, max and counts merge exactly and a range's split depends on the range alone, so the tree does not
+//     depend on the number of threads or on who builds what (tests/cpp/builder_check.cpp).
 // Any tree whose boxes enclose their shapes gives the same hits; only the order in which equal-t hits
 // are found depends on it, which is why the oracle's fp32 mode restates this builder too.
 HostNodes build_sah(const rt_shape* shapes, int64_t n, int leaf_size);
