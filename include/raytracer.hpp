@@ -226,6 +226,7 @@ inline rt_image_spec spec_of(const ImageSpec& is) {
 
 // GenerateImage, raytracer.go:58-107.  Errors (the reference panics) are thrown as std::runtime_error.
 inline RGBA GenerateImage(const ImageSpec& imageSpec, const Scene& scene, rt_stats* stats = nullptr) {
+    if (rt_init(0) != RT_OK) throw std::runtime_error(rt_last_error());  // first: the runtime's start-up then runs under the flattening
     detail::Flat flat(scene);
     const rt_image_spec spec = detail::spec_of(imageSpec);
     std::printf("Building BoundingVolumeHierarchy\n");  // accelerationstructures.go:28

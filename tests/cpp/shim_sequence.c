@@ -1,6 +1,6 @@
 /* The cgo shim's call sequence (generateImageHIP) in plain C, for a box without a Go toolchain:
  * tables in C-allocated memory (calloc, as the shim's C.calloc), image-texture pixels copied into C memory (as
- * C.CBytes), then rt_scene_create(desc, 0, &scene) -> rt_render(scene, &spec, NULL, pix, &stats) ->
+ * C.CBytes) after rt_init(0), then rt_scene_create(desc, 0, &scene) -> rt_render(scene, &spec, NULL, pix, &stats) ->
  * rt_scene_destroy(scene), errors read through rt_last_error() on the calling thread.
  *   shim_sequence <scene.bin> <out.rgba>
  * scene.bin (written by tests/test_cpp_mirror.py from the flattened ExampleRegression):
@@ -19,6 +19,7 @@ static void need(int ok, const char* what) {
 
 int main(int argc, char** argv) {
     need(argc == 3, "usage: shim_sequence scene.bin out.rgba");
+    if (rt_init(0) != RT_OK) { fprintf(stderr, "panic: %s\n", rt_last_error()); return 1; } /* first: starts the runtime's warm-up */
     FILE* f = fopen(argv[1], "rb");
     need(f != NULL, "cannot open the scene file");
     int64_t n[4];
