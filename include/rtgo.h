@@ -230,8 +230,8 @@ int rt_generate_image(const rt_scene_desc* desc, const rt_image_spec* spec,
 
 /* ---- one frame on several GPUs of one node, behind one blocking call ----------------------
  * Replaces the goroutine fan-out inside GenerateImage (raytracer.go:73-87: WorkerCount workers fed from one
- * job channel) with one host thread per device: the scene is replicated (rt_multi_create = rt_scene_create per
- * device, all at once), share r of the frame — tiles k with k % n == r (RT_PART_TILES) or samples
+ * job channel) with one host thread per device: the scene is replicated (rt_multi_create builds the tree and the
+ * tables once on the host and uploads them to all devices at the same time), share r of the frame — tiles k with k % n == r (RT_PART_TILES) or samples
  * [r*spp/n, (r+1)*spp/n) (RT_PART_SAMPLES) — is rendered on devices[r] into that device's fp32 accumulation
  * buffer, the buffers are summed onto devices[0] with one ncclReduce over xGMI (communicators from
  * ncclCommInitAll, librccl opened on first need), devices[0] divides, quantises (raytracer.go:93-96,119) and

@@ -1038,9 +1038,21 @@ int rt_init(int device) {
     return RT_OK;
 }
 
-static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene** out) {
-    if (!desc || !out) return fail(RT_ERR_INVALID, "desc/out is NULL");
-    *out = nullptr;
+// ---- scene creation, in the steps rt_scene_create and rt_multi_create put together ----
+// RTGO_TIMING=1: the phases of scene creation on stderr (host tree build, flattening, tables, uploads)
+struct Laps {
+    bool on = std::getenv("RTGO_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void operator()(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[rtgo] scene create: %-10s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+
+static int validate_desc(const rt_scene_desc* desc) {
+    if (!desc) return fail(RT_ERR_INVALID, "desc is NULL");
     if (desc->n_shapes < 0 || desc->n_materials < 0 || desc->n_textures < 0 || desc->n_lights < 0)
         return fail(RT_ERR_INVALID, "negative table size");
     if (desc->n_shapes >= kMaxChildRecords) return fail(RT_ERR_LIMIT, "scene has " + std::to_string(desc->n_shapes) + " shapes; the limit is 2^24 - 1 (a leaf keeps 24 bits for its first shape)");
@@ -1072,46 +1084,20 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     }
     for (int64_t i = 0; i < desc->n_lights; ++i)
         if (desc->lights[i].kind < RT_LIGHT_AMBIENT || desc->lights[i].kind > RT_LIGHT_SPOT) return fail(RT_ERR_INVALID, "unknown light kind");
-    const auto t0 = std::chrono::steady_clock::now();
-    int rc = rt_init(device);
-    if (rc != RT_OK) return rc;
+    return RT_OK;
+}
 
-    // RTGO_TIMING=1: the phases of scene creation on stderr (host tree build, flattening, tables, uploads)
-    const bool timing = std::getenv("RTGO_TIMING") != nullptr;
-    auto lap = [&, last = t0](const char* what) mutable {
-        if (!timing) return;
-        const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[rtgo] scene create: %-10s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
-        last = now;
-    };
-    lap("rt_init");
-    rt_scene* s = new rt_scene();
-    struct Guard {  // an exception (std::bad_alloc in a table, std::system_error from a thread) must not leak the device buffers
-        rt_scene* s;
-        ~Guard() { if (s) rt_scene_destroy(s); }
-    } guard{s};
-    s->device = device;
-    // Declared after the guard: whichever way this function is left, the thread has ended (a std::async future waits
-    // in its destructor) before the guard releases the scene.
-    std::future<std::pair<hipError_t, const char*>> lane_setup = std::async(std::launch::async, [s, device]() -> std::pair<hipError_t, const char*> {
-#define HIP_TRY_L(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return {e_, #expr}; } while (0)
-        HIP_TRY_L(hipSetDevice(device));
-        for (int l = 0; l < kLanes; ++l) {
-            Lane& ln = s->lanes[l];
-            ln.ev_ok = true;  // from here on rt_scene_destroy() releases whatever of the lane exists
-            ln.h_counter_words = (size_t)(3 * kStaticDepth + 8);
-            HIP_TRY_L(hipHostMalloc((void**)&ln.h_counters, kSnapshots * ln.h_counter_words * sizeof(uint32_t)));
-            for (auto& e : ln.ev_snap) HIP_TRY_L(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            for (auto& e : ln.ev_frame) HIP_TRY_L(hipEventCreate(&e));
-            HIP_TRY_L(hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
-            if (l > 0) HIP_TRY_L(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
-        }
-        HIP_TRY_L(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-        for (auto& e : s->ev_wall) HIP_TRY_L(hipEventCreate(&e));
-        return {hipSuccess, ""};
-#undef HIP_TRY_L
-    });
+// What every device's copy of a scene is uploaded from: built once on the host, whatever the number of devices.
+struct HostScene {
     FlatTree flat;
+    size_t prim_words = 0;
+    std::unique_ptr<float[]> prims, tprims;
+    std::vector<DMaterial> mats;
+    std::vector<DLight> lights;
+    int n_pos = 0;
+};
+
+static int build_host_scene(const rt_scene_desc* desc, HostScene* h, Laps& lap) {
     {
         const char* err = nullptr;
         // shapes per leaf: 1 = the reference's tree; larger leaves trade box tests for shape tests
@@ -1124,7 +1110,7 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
                                                 ? build_octree(desc->shapes, desc->n_shapes)
                                                 : build_sah(desc->shapes, desc->n_shapes, leaf_size);
         lap("tree");
-        if (!flatten_octree(nodes, leaf_size, &flat, &err)) return fail(RT_ERR_LIMIT, err);
+        if (!flatten_octree(nodes, leaf_size, &h->flat, &err)) return fail(RT_ERR_LIMIT, err);
         lap("flatten");
     }
     lap("free nodes");
@@ -1132,14 +1118,17 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
     // tprims: the same records for the intersection tests, with the triangle's edges e1 = B - A, e2 = C - A (fp32
     // differences of the fp32 vertices, exactly what the tests would compute) in place of B and C
     // (not zeroed first: the threads write all 12 words of every record, and the pages are theirs to touch)
-    const size_t prim_words = (size_t)desc->n_shapes * 12 + 12;
-    std::unique_ptr<float[]> prims(new float[prim_words]), tprims(new float[prim_words]);
+    const size_t prim_words = h->prim_words = (size_t)desc->n_shapes * 12 + 12;
+    h->prims.reset(new float[prim_words]);
+    h->tprims.reset(new float[prim_words]);
+    float* const prims = h->prims.get();
+    float* const tprims = h->tprims.get();
     for (size_t k = prim_words - 12; k < prim_words; ++k) prims[k] = tprims[k] = 0.0f;  // the padding record
     host_chunks(desc->n_shapes, [&](int64_t q0, int64_t q1) {
         for (int64_t q = q0; q < q1; ++q) {
-            const rt_shape& s = desc->shapes[flat.order[(size_t)q]];
-            float* p = prims.get() + (size_t)q * 12;
-            float* t = tprims.get() + (size_t)q * 12;
+            const rt_shape& s = desc->shapes[h->flat.order[(size_t)q]];
+            float* p = prims + (size_t)q * 12;
+            float* t = tprims + (size_t)q * 12;
             for (int k = 0; k < 12; ++k) p[k] = t[k] = 0.0f;
             uint32_t bits = (uint32_t)s.material << 2;
             if (s.kind == RT_SHAPE_TRIANGLE) {
@@ -1158,7 +1147,8 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
             std::memcpy(&t[9], &bits, 4);
         }
     });
-    std::vector<DMaterial> mats((size_t)desc->n_materials + 1);
+    std::vector<DMaterial>& mats = h->mats;
+    mats.assign((size_t)desc->n_materials + 1, DMaterial{});
     for (int64_t i = 0; i < desc->n_materials; ++i) {
         const rt_material& m = desc->materials[i];
         DMaterial& d = mats[(size_t)i];
@@ -1168,7 +1158,67 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
         d.param = (float)m.param;
     }
 
+
+    std::vector<DLight>& lights = h->lights;
+    lights.assign((size_t)desc->n_lights + 1, DLight{});
+    int n_pos = 0;
+    for (int64_t i = 0; i < desc->n_lights; ++i) {
+        const rt_light& l = desc->lights[i];
+        DLight& d = lights[(size_t)i];
+        d.kind = l.kind;
+        d.color[0] = (float)l.color.x; d.color[1] = (float)l.color.y; d.color[2] = (float)l.color.z;
+        d.pos[0] = (float)l.position.x; d.pos[1] = (float)l.position.y; d.pos[2] = (float)l.position.z;
+        double ld[3] = {l.look_at.x - l.position.x, l.look_at.y - l.position.y, l.look_at.z - l.position.z};
+        if (l.kind == RT_LIGHT_SPOT) {  // light.go:127: Unit(LookAt - Position)
+            if (ld[0] == 0 && ld[1] == 0 && ld[2] == 0) ld[0] = ld[1] = ld[2] = NAN;
+            else { const double k = 1 / std::hypot(ld[0], std::hypot(ld[1], ld[2])); ld[0] *= k; ld[1] *= k; ld[2] *= k; }
+        } else { ld[0] = ld[1] = ld[2] = 0; }
+        d.look_dir[0] = (float)ld[0]; d.look_dir[1] = (float)ld[1]; d.look_dir[2] = (float)ld[2];
+        d.intensity = (float)l.intensity; d.spec_intensity = (float)l.specular_intensity;
+        d.cos_angle = (float)std::cos(l.angle_deg * M_PI / 180.0);
+        d.decay = (float)l.decay;
+        if (l.kind != RT_LIGHT_AMBIENT) ++n_pos;
+    }
+    h->n_pos = n_pos;
     lap("tables");
+    return RT_OK;
+}
+
+using LaneSetup = std::future<std::pair<hipError_t, const char*>>;
+// A device's scene before its tables: rt_init (which starts the runtime's warm-up there) and a thread that makes the
+// lanes' events, streams and pinned counters while the host builds the tree.  The caller owns *out from here on and
+// lets `lane_setup` go (a std::async future waits in its destructor) BEFORE it destroys the scene.
+static int begin_scene(int device, rt_scene** out, LaneSetup* lane_setup_out) {
+    int rc = rt_init(device);
+    if (rc != RT_OK) return rc;
+    rt_scene* s = new rt_scene();
+    s->device = device;
+    *out = s;
+    *lane_setup_out = std::async(std::launch::async, [s, device]() -> std::pair<hipError_t, const char*> {
+#define HIP_TRY_L(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return {e_, #expr}; } while (0)
+        HIP_TRY_L(hipSetDevice(device));
+        for (int l = 0; l < kLanes; ++l) {
+            Lane& ln = s->lanes[l];
+            ln.ev_ok = true;  // from here on rt_scene_destroy() releases whatever of the lane exists
+            ln.h_counter_words = (size_t)(3 * kStaticDepth + 8);
+            HIP_TRY_L(hipHostMalloc((void**)&ln.h_counters, kSnapshots * ln.h_counter_words * sizeof(uint32_t)));
+            for (auto& e : ln.ev_snap) HIP_TRY_L(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto& e : ln.ev_frame) HIP_TRY_L(hipEventCreate(&e));
+            HIP_TRY_L(hipEventCreateWithFlags(&ln.ev_join, hipEventDisableTiming));
+            if (l > 0) HIP_TRY_L(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        }
+        HIP_TRY_L(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        for (auto& e : s->ev_wall) HIP_TRY_L(hipEventCreate(&e));
+        return {hipSuccess, ""};
+#undef HIP_TRY_L
+    });
+    return RT_OK;
+}
+
+// The tables of `h` uploaded to the scene's device.
+static int finish_scene(const rt_scene_desc* desc, const HostScene& h, rt_scene* s, LaneSetup* lane_setup, Laps& lap) {
+    const int device = s->device;
+    HIP_TRY(hipSetDevice(device));
     wait_warm_up(device);  // started by rt_init
     lap("hip warm");
     s->from = desc->camera_look_from; s->at = desc->camera_look_at; s->up = desc->camera_up;
@@ -1201,75 +1251,78 @@ static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene*
         }
     }
     lap("textures");
-    std::vector<DLight> lights((size_t)desc->n_lights + 1);
-    int n_pos = 0;
-    for (int64_t i = 0; i < desc->n_lights; ++i) {
-        const rt_light& l = desc->lights[i];
-        DLight& d = lights[(size_t)i];
-        d.kind = l.kind;
-        d.color[0] = (float)l.color.x; d.color[1] = (float)l.color.y; d.color[2] = (float)l.color.z;
-        d.pos[0] = (float)l.position.x; d.pos[1] = (float)l.position.y; d.pos[2] = (float)l.position.z;
-        double ld[3] = {l.look_at.x - l.position.x, l.look_at.y - l.position.y, l.look_at.z - l.position.z};
-        if (l.kind == RT_LIGHT_SPOT) {  // light.go:127: Unit(LookAt - Position)
-            if (ld[0] == 0 && ld[1] == 0 && ld[2] == 0) ld[0] = ld[1] = ld[2] = NAN;
-            else { const double k = 1 / std::hypot(ld[0], std::hypot(ld[1], ld[2])); ld[0] *= k; ld[1] *= k; ld[2] *= k; }
-        } else { ld[0] = ld[1] = ld[2] = 0; }
-        d.look_dir[0] = (float)ld[0]; d.look_dir[1] = (float)ld[1]; d.look_dir[2] = (float)ld[2];
-        d.intensity = (float)l.intensity; d.spec_intensity = (float)l.specular_intensity;
-        d.cos_angle = (float)std::cos(l.angle_deg * M_PI / 180.0);
-        d.decay = (float)l.decay;
-        if (l.kind != RT_LIGHT_AMBIENT) ++n_pos;
-    }
-
-    const size_t rec_bytes = (flat.records.size() + 1) * sizeof(ChildRecord);
-    if (flat.qblocks.empty()) return bail(fail(RT_ERR_DEVICE, "flattener produced no quantised blocks"));
+    const size_t rec_bytes = (h.flat.records.size() + 1) * sizeof(ChildRecord);
+    if (h.flat.qblocks.empty()) return bail(fail(RT_ERR_DEVICE, "flattener produced no quantised blocks"));
     HIP_TRY_S(hipMalloc(&s->d_recs, rec_bytes));
     HIP_TRY_S(hipMemset(s->d_recs, 0, rec_bytes));  // the padding record is fetched (and masked out) for trailing absent slots
-    if (!flat.records.empty()) HIP_TRY_S(hipMemcpy(s->d_recs, flat.records.data(), flat.records.size() * sizeof(ChildRecord), hipMemcpyHostToDevice));
-    HIP_TRY_S(hipMalloc(&s->d_qblocks, flat.qblocks.size() * sizeof(uint32_t)));
-    HIP_TRY_S(hipMemcpy(s->d_qblocks, flat.qblocks.data(), flat.qblocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY_S(hipMalloc(&s->d_prims, prim_words * sizeof(float)));
-    HIP_TRY_S(hipMemcpy(s->d_prims, prims.get(), prim_words * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY_S(hipMalloc(&s->d_tprims, prim_words * sizeof(float)));
-    HIP_TRY_S(hipMemcpy(s->d_tprims, tprims.get(), prim_words * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY_S(hipMalloc(&s->d_prim_ids, (flat.order.size() + 1) * sizeof(int32_t)));
-    if (!flat.order.empty()) HIP_TRY_S(hipMemcpy(s->d_prim_ids, flat.order.data(), flat.order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY_S(hipMalloc(&s->d_block_first, flat.block_first.size() * sizeof(uint32_t)));
-    HIP_TRY_S(hipMemcpy(s->d_block_first, flat.block_first.data(), flat.block_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY_S(hipMalloc(&s->d_block_box, flat.block_box.size() * sizeof(float)));
-    HIP_TRY_S(hipMemcpy(s->d_block_box, flat.block_box.data(), flat.block_box.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY_S(hipMalloc(&s->d_mats, mats.size() * sizeof(DMaterial)));
-    HIP_TRY_S(hipMemcpy(s->d_mats, mats.data(), mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
+    if (!h.flat.records.empty()) HIP_TRY_S(hipMemcpy(s->d_recs, h.flat.records.data(), h.flat.records.size() * sizeof(ChildRecord), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_qblocks, h.flat.qblocks.size() * sizeof(uint32_t)));
+    HIP_TRY_S(hipMemcpy(s->d_qblocks, h.flat.qblocks.data(), h.flat.qblocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_prims, h.prim_words * sizeof(float)));
+    HIP_TRY_S(hipMemcpy(s->d_prims, h.prims.get(), h.prim_words * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_tprims, h.prim_words * sizeof(float)));
+    HIP_TRY_S(hipMemcpy(s->d_tprims, h.tprims.get(), h.prim_words * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_prim_ids, (h.flat.order.size() + 1) * sizeof(int32_t)));
+    if (!h.flat.order.empty()) HIP_TRY_S(hipMemcpy(s->d_prim_ids, h.flat.order.data(), h.flat.order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_block_first, h.flat.block_first.size() * sizeof(uint32_t)));
+    HIP_TRY_S(hipMemcpy(s->d_block_first, h.flat.block_first.data(), h.flat.block_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_block_box, h.flat.block_box.size() * sizeof(float)));
+    HIP_TRY_S(hipMemcpy(s->d_block_box, h.flat.block_box.data(), h.flat.block_box.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_mats, h.mats.size() * sizeof(DMaterial)));
+    HIP_TRY_S(hipMemcpy(s->d_mats, h.mats.data(), h.mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_texs, texs.size() * sizeof(DTexture)));
     HIP_TRY_S(hipMemcpy(s->d_texs, texs.data(), texs.size() * sizeof(DTexture), hipMemcpyHostToDevice));
-    HIP_TRY_S(hipMalloc(&s->d_lights, lights.size() * sizeof(DLight)));
-    HIP_TRY_S(hipMemcpy(s->d_lights, lights.data(), lights.size() * sizeof(DLight), hipMemcpyHostToDevice));
+    HIP_TRY_S(hipMalloc(&s->d_lights, h.lights.size() * sizeof(DLight)));
+    HIP_TRY_S(hipMemcpy(s->d_lights, h.lights.data(), h.lights.size() * sizeof(DLight), hipMemcpyHostToDevice));
 
     lap("uploads");
     // traversal stack spill: worst case 7 pending siblings per level, beyond the LDS part
-    const int spill = flat.stack_bound + 1 > kLdsStackDepth ? flat.stack_bound + 1 - kLdsStackDepth : 0;  // +1: the nearest child is pushed, then popped
+    const int spill = h.flat.stack_bound + 1 > kLdsStackDepth ? h.flat.stack_bound + 1 - kLdsStackDepth : 0;  // +1: the nearest child is pushed, then popped
     s->spill = spill;  // the region itself is sized by ensure_overflow() for the grids a call really launches
 
     s->d.recs = (const float4*)s->d_recs; s->d.qblocks = (const uint4*)s->d_qblocks; s->d.prims = (const float4*)s->d_prims; s->d.tprims = (const float4*)s->d_tprims; s->d.prim_ids = (const int*)s->d_prim_ids; s->d.block_first = (const uint32_t*)s->d_block_first; s->d.block_box = (const float4*)s->d_block_box;
     s->d.materials = (const DMaterial*)s->d_mats; s->d.textures = (const DTexture*)s->d_texs;
     s->d.lights = (const DLight*)s->d_lights;
-    s->d.n_lights = (int)desc->n_lights; s->d.n_pos_lights = n_pos; s->d.root_ref = flat.root_ref;
+    s->d.n_lights = (int)desc->n_lights; s->d.n_pos_lights = h.n_pos; s->d.root_ref = h.flat.root_ref;
     {  // the lanes' events, streams and pinned counters: made by a thread of their own since the tree build began
-        const std::pair<hipError_t, const char*> made = lane_setup.get();
+        const std::pair<hipError_t, const char*> made = lane_setup->get();
         if (made.first != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string(made.second) + ": " + hipGetErrorString(made.first)));
     }
 
-    s->info.n_shapes = desc->n_shapes; s->info.n_inner_nodes = flat.n_inner;
-    s->info.n_child_records = (int64_t)flat.records.size();
-    s->info.tree_depth = flat.depth; s->info.stack_bound = flat.stack_bound;
-    s->info.device_bytes = (int64_t)(rec_bytes + flat.qblocks.size() * 4 + prim_words * 4 + prim_words * 4 + mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
-                                     lights.size() * sizeof(DLight)) + tex_bytes;  // + the spill region, see ensure_overflow()
+    s->info.n_shapes = desc->n_shapes; s->info.n_inner_nodes = h.flat.n_inner;
+    s->info.n_child_records = (int64_t)h.flat.records.size();
+    s->info.tree_depth = h.flat.depth; s->info.stack_bound = h.flat.stack_bound;
+    s->info.device_bytes = (int64_t)(rec_bytes + h.flat.qblocks.size() * 4 + h.prim_words * 4 + h.prim_words * 4 + h.mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
+                                     h.lights.size() * sizeof(DLight)) + tex_bytes;  // + the spill region, see ensure_overflow()
     lap("events");
-    s->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    guard.s = nullptr;
-    *out = s;
     return RT_OK;
 #undef HIP_TRY_S
+}
+
+static int rt_scene_create_impl(const rt_scene_desc* desc, int device, rt_scene** out) {
+    if (!out) return fail(RT_ERR_INVALID, "desc/out is NULL");
+    *out = nullptr;
+    int rc = validate_desc(desc);
+    if (rc != RT_OK) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    Laps lap;
+    struct Guard {  // an exception (std::bad_alloc in a table, std::system_error from a thread) must not leak the device buffers
+        rt_scene* s = nullptr;
+        ~Guard() { if (s) rt_scene_destroy(s); }
+    } guard;
+    LaneSetup lane_setup;  // declared after the guard: its thread has ended before the guard releases the scene
+    rc = begin_scene(device, &guard.s, &lane_setup);
+    if (rc != RT_OK) return rc;
+    lap("rt_init");
+    HostScene host;
+    rc = build_host_scene(desc, &host, lap);
+    if (rc != RT_OK) return rc;
+    rc = finish_scene(desc, host, guard.s, &lane_setup, lap);
+    if (rc != RT_OK) return rc;
+    guard.s->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out = guard.s;
+    guard.s = nullptr;
+    return RT_OK;
 }
 
 void rt_scene_destroy(rt_scene* s) {
@@ -1797,11 +1850,27 @@ static int rt_multi_create_impl(const rt_scene_desc* desc, const int32_t* device
     for (int a = 0; a < n; ++a)
         for (int b = a + 1; b < n; ++b)
             if (devices[a] == devices[b]) m->distinct = false;
-    // the replicas: tree build + upload per device, all at once (the builds are deterministic: every replica holds the same tree)
-    int rc = on_every_rank(n, [&](int r) {
-        int c = rt_scene_create(desc, m->devices[(size_t)r], &m->scenes[(size_t)r]);
+    // The replicas: the tree and the tables are built ONCE on the host (while every device's runtime warm-up and lane
+    // set-up run on threads of their own) and then uploaded to all devices at the same time.
+    int rc = validate_desc(desc);
+    if (rc != RT_OK) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    Laps lap;
+    std::vector<LaneSetup> lane_setups((size_t)n);  // declared after the guard: their threads end before it destroys the scenes
+    for (int r = 0; r < n; ++r) {
+        rc = begin_scene(m->devices[(size_t)r], &m->scenes[(size_t)r], &lane_setups[(size_t)r]);
+        if (rc != RT_OK) return rc;
+    }
+    lap("rt_init");
+    HostScene host;
+    rc = build_host_scene(desc, &host, lap);
+    if (rc != RT_OK) return rc;
+    rc = on_every_rank(n, [&](int r) {
+        Laps mine;
+        mine.on = lap.on && r == 0;
+        int c = finish_scene(desc, host, m->scenes[(size_t)r], &lane_setups[(size_t)r], mine);
         if (c != RT_OK) return c;
-        HIP_TRY(hipSetDevice(m->devices[(size_t)r]));
+        m->scenes[(size_t)r]->ms_build = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         HIP_TRY(hipStreamCreateWithFlags(&m->streams[(size_t)r], hipStreamNonBlocking));
         return RT_OK;
     });
