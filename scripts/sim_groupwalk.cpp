@@ -574,6 +574,126 @@ extern "C" int sim_ball_beam(const orc_scene* s, const rt_image_spec* spec, uint
     return 0;
 }
 
+// ---- sub-beams: the pairs the ball beam does not prove clear, tried again in groups of `group` repetitions ----------
+// A group's beam is the box of ITS jittered light positions (not the whole ball): { p + s (D' + j) }, j within the
+// group's per-axis range.  out: [0] non-clear pairs, [1] their rays, [2] sub-beams walked, [3] clear sub-beams,
+// [4] rays of clear sub-beams, [5] block visits of all sub-beam walks, [6] per-ray visits of the rays in clear sub-beams,
+// [7] per-ray visits of all rays of non-clear pairs, [8] clear sub-beams holding an occluded ray (must be 0),
+// [9] occluded rays, [10] sub-beam visits in pairs whose rays are all occluded, [11] rays of such pairs,
+// [12] per-ray shape tests of the rays in clear sub-beams, [13] per-ray shape tests of all rays of non-clear pairs
+extern "C" int sim_sub_beam(const orc_scene* s, const rt_image_spec* spec, uint64_t seed, double R, int group, double* out) {
+    const Scene& sc = s->sc;
+    const int W = spec->width, H = spec->height, reps = spec->soft_shadow_monte_carlo_repetitions;
+    const CameraF64 c64 = new_camera(sc, W, H);
+    const Camera<float> cf = narrow_camera<float>(c64);
+    const Tables<float>& T = sc.t32;
+    Node* root = effective(sc.wide_root);
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    if (root->as_leaf) return 0;
+    for (int row = 0; row < H; ++row)
+        for (int i = 0; i < W; ++i) {
+            const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(row * W + i), 0u};
+            const Ray<float> r = camera_ray(cf, W, H, i, H - 1 - row, key);
+            Hit<float> hit;
+            if (!trace_stack_f32(sc, r, 0.0f, FLT_MAX, false, hit, nullptr)) continue;
+            const Shape<float>& sh = T.shapes[hit.shape];
+            const Material<float>& m = T.materials[sh.material];
+            if (m.kind != RT_MAT_PHONGBLINN) continue;
+            int lpos = -1;
+            for (size_t li = 0; li < T.lights.size(); ++li) {
+                const Light<float>& L = T.lights[li];
+                if (L.kind == RT_LIGHT_AMBIENT) continue;
+                ++lpos;
+                const V3<float> ldir = unit(sub(L.pos, hit.p));
+                const float inten = saturate(dot(hit.normal, ldir));
+                const V3<float> h = unit(add(ldir, r.d));
+                const float si = std::pow(saturate(dot(hit.normal, h)), m.param);
+                if (inten == 0.0f && (si == 0.0f || (m.spec.x == 0 && m.spec.y == 0 && m.spec.z == 0))) continue;
+                struct PR { V3<float> target; bool occ; double visits, shapes; };
+                std::vector<PR> prays;
+                for (int k = 0; k < reps; ++k) {
+                    const V3<float> jit = scale(0.25f, random_in_unit_sphere<float>(key, 0, P_SHADOW, (uint32_t)(lpos * reps + k)));
+                    const V3<float> shifted = add(L.pos, jit);
+                    if (L.kind == RT_LIGHT_SPOT && !(dot(L.look_dir, unit(sub(hit.p, shifted))) >= L.cos_angle)) continue;
+                    const V3<float> ld = sub(shifted, hit.p);
+                    const float d = norm(ld);
+                    TraceCounters tc; Hit<float> hh;
+                    const bool oc = trace_stack_f32(sc, Ray<float>{hit.p, scale(1.0f / d, ld)}, 0.01f, d, true, hh, &tc);
+                    prays.push_back(PR{shifted, oc, (double)tc.inner, (double)tc.leaf});
+                }
+                if (prays.empty()) continue;
+                const double p[3] = {hit.p.x, hit.p.y, hit.p.z};
+                // walk of the beam whose directions span [dlo, dhi] per axis; true = met no leaf box
+                auto beam_clear = [&](const double* dlo, const double* dhi, double* visits) {
+                    double len2 = 0;
+                    for (int a = 0; a < 3; ++a) { const double far = std::max(std::fabs(dlo[a]), std::fabs(dhi[a])); len2 += far * far; }
+                    const double s0 = 0.01 / std::sqrt(len2) * 0.999, s1 = 1.0001;
+                    const double mid[3] = {(dlo[0] + dhi[0]) * 0.5, (dlo[1] + dhi[1]) * 0.5, (dlo[2] + dhi[2]) * 0.5};
+                    const int sign = (mid[0] < 0 ? 1 : 0) | (mid[1] < 0 ? 2 : 0) | (mid[2] < 0 ? 4 : 0);
+                    auto meets = [&](const float* lo, const float* hi) {
+                        double a = s0, b = s1;
+                        for (int ax = 0; ax < 3; ++ax) {
+                            const double c1 = dlo[ax], c2 = dhi[ax];
+                            const double h1 = (double)hi[ax] - p[ax], l1 = (double)lo[ax] - p[ax];
+                            if (c1 > 0) b = std::min(b, h1 / c1); else if (c1 < 0) a = std::max(a, h1 / c1); else if (h1 < 0) return false;
+                            if (c2 > 0) a = std::max(a, l1 / c2); else if (c2 < 0) b = std::min(b, l1 / c2); else if (l1 > 0) return false;
+                        }
+                        return a <= b;
+                    };
+                    std::vector<Node*> stack;
+                    Node* cur = root;
+                    while (cur) {
+                        *visits += 1;
+                        Node* pending[8]; int np = 0;
+                        for (int k = 0; k < 8; ++k) {
+                            Node* e = cur->slot[k ^ sign];
+                            if (!e || !meets(e->fmin, e->fmax)) continue;
+                            if (e->as_leaf) return false;
+                            pending[np++] = e;
+                        }
+                        for (int q = np - 1; q >= 1; --q) stack.push_back(pending[q]);
+                        if (np > 0) { cur = pending[0]; continue; }
+                        if (stack.empty()) break;
+                        cur = stack.back(); stack.pop_back();
+                    }
+                    return true;
+                };
+                {
+                    double dlo[3], dhi[3], v = 0;
+                    const double Lp[3] = {L.pos.x, L.pos.y, L.pos.z};
+                    for (int a = 0; a < 3; ++a) { dlo[a] = Lp[a] - p[a] - R; dhi[a] = Lp[a] - p[a] + R; }
+                    if (beam_clear(dlo, dhi, &v)) continue;  // the ball beam settles this pair
+                }
+                out[0] += 1; out[1] += (double)prays.size();
+                int n_occ = 0; double all_visits = 0;
+                for (const PR& q : prays) { n_occ += q.occ ? 1 : 0; all_visits += q.visits; out[13] += q.shapes; }
+                out[7] += all_visits; out[9] += n_occ;
+                const bool dark = n_occ == (int)prays.size();
+                if (dark) out[11] += (double)prays.size();
+                for (size_t g0 = 0; g0 < prays.size(); g0 += (size_t)group) {
+                    const size_t g1 = std::min(prays.size(), g0 + (size_t)group);
+                    double dlo[3] = {1e300, 1e300, 1e300}, dhi[3] = {-1e300, -1e300, -1e300};
+                    for (size_t k = g0; k < g1; ++k) {
+                        const double t[3] = {prays[k].target.x, prays[k].target.y, prays[k].target.z};
+                        for (int a = 0; a < 3; ++a) { dlo[a] = std::min(dlo[a], t[a] - p[a]); dhi[a] = std::max(dhi[a], t[a] - p[a]); }
+                    }
+                    for (int a = 0; a < 3; ++a) { dlo[a] -= 1e-5; dhi[a] += 1e-5; }
+                    double v = 0;
+                    const bool clear = beam_clear(dlo, dhi, &v);
+                    out[2] += 1; out[5] += v;
+                    if (dark) out[10] += v;
+                    if (!clear) continue;
+                    out[3] += 1;
+                    for (size_t k = g0; k < g1; ++k) {
+                        out[4] += 1; out[6] += prays[k].visits; out[12] += prays[k].shapes;
+                        if (prays[k].occ) out[8] += 1;
+                    }
+                }
+            }
+        }
+    return 0;
+}
+
 // ---- would the occluder of a pair's CENTRAL ray (p -> the light's centre) decide its other rays? ---------------
 // out: [0] rays of pairs that are not clear by sim_ball_beam's criterion (approximated: pairs with an occluded ray or
 // whose central ray is occluded are surely not clear; lit pairs are left out), [1] occluded rays among them,
