@@ -9,7 +9,8 @@
 //   - every quantised block (QBlock, the shadow-ray walk's copy of the tree) decodes, in exact arithmetic, to boxes
 //     that enclose the child records' fp32 boxes, names the same leaf shapes and the blocks of the same inner children;
 //   - the SAH tree of a scene long enough for the builder's threads (chunked sweeps and forked halves) is
-//     byte-identical for 1, 3 and 7 threads.
+//     byte-identical for 1, 3, 7 and 16 threads;
+//   - a coordinate of -0.0 builds the tree that +0.0 builds (the SAH builder's min / max rely on it).
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -171,19 +172,34 @@ int main() {
             v.push_back(i % 11 ? tri(off + 10 * u(rng), 10 * u(rng), 10 * u(rng), 0.05) : sphere(off + 10 * u(rng), 10 * u(rng), 10 * u(rng), 0.03));
         }
         FlatTree ref;
-        for (const char* threads : {"1", "3", "7"}) {
+        for (const char* threads : {"1", "3", "7", "16"}) {
             setenv("RTGO_BUILD_THREADS", threads, 1);
             FlatTree t;
             const char* err = nullptr;
             CHECK(flatten_octree(build_sah(v.data(), (int64_t)v.size(), 6), 6, &t, &err), "flatten failed: %s", err ? err : "?");
             if (threads[0] == '1') { ref = t; continue; }
             CHECK(t.records.size() == ref.records.size() && t.order == ref.order && t.root_ref == ref.root_ref && t.stack_bound == ref.stack_bound &&
-                      t.qblocks == ref.qblocks &&
+                      t.qblocks == ref.qblocks && t.block_first == ref.block_first && t.block_box == ref.block_box &&
                       std::memcmp(t.records.data(), ref.records.data(), t.records.size() * sizeof(ChildRecord)) == 0,
                   "SAH tree differs between 1 and %s threads", threads);
         }
         unsetenv("RTGO_BUILD_THREADS");
         check_scene("two clusters, threaded", v, 6);
+    }
+    {   // -0.0 among the coordinates: the same tree as with +0.0, whatever the threads (the builder's one-instruction
+        // min / max return either argument of an equal pair)
+        std::vector<rt_shape> plus, minus;
+        for (int i = 0; i < 4000; ++i) {
+            const double x = (i % 40) * 0.25 - 5.0, y = (i / 40) * 0.25 - 12.5;
+            rt_shape t = tri(x, y, 0, 0.2);
+            plus.push_back(t);
+            for (rt_vec3* v : {&t.a, &t.b, &t.c}) { if (v->x == 0) v->x = -0.0; if (v->y == 0) v->y = -0.0; if (v->z == 0) v->z = -0.0; }
+            minus.push_back(t);
+        }
+        FlatTree tp, tm;
+        const char* err = nullptr;
+        CHECK(flatten_octree(build_sah(plus.data(), (int64_t)plus.size(), 6), 6, &tp, &err) && flatten_octree(build_sah(minus.data(), (int64_t)minus.size(), 6), 6, &tm, &err), "flatten failed");
+        CHECK(tp.order == tm.order && tp.qblocks == tm.qblocks && tp.records.size() == tm.records.size(), "-0.0 coordinates change the SAH tree");
     }
     {   // equal centroids where the reference's 1e-10 jitter is below one ulp: its insertion octree never ends
         // (accelerationstructures.go:226-279); build_octree refuses the scene, build_sah (no jitter, ranges halved
