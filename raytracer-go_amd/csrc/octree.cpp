@@ -214,9 +214,9 @@ struct SahBuilder {
     int leaf_size;
     // depth: SAH may split 1 : n-1 again and again on adversarial input; beyond kMaxSahDepth levels the
     // range is halved instead, so the recursion stays O(kMaxSahDepth + log n) deep.
-    // threads: how many threads this subtree may use; a split shares them out by the halves' lengths.  The
-    // two halves of a range touch disjoint items and only the node numbers depend on the interleaving;
-    // emit() follows left/right links, so the tree that comes out is the same for any number of threads.
+    // threads: > 1 only on the thread that builds the top of the tree (chunked sweeps, see build_all); the other
+    // ranges are tasks.  The two halves of a range touch disjoint items and only the node numbers depend on the
+    // interleaving; emit() follows left/right links, so the tree that comes out is the same for any number of threads.
     static constexpr int kBins = 16;
     struct Bin { double lo[3], hi[3]; int n; };
     struct Box {  // of a range: its items' bounds and their centroids' bounds
