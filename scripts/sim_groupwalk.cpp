@@ -574,6 +574,104 @@ extern "C" int sim_ball_beam(const orc_scene* s, const rt_image_spec* spec, uint
     return 0;
 }
 
+// ---- in which order should an any-hit walk enter the children it meets? ---------------------------------------
+// mode 0: ray order by octant (slot k ^ sign, what the device does); 1: longest chord (tf - tn) first; 2: nearest entry
+// first; 3: most shapes first; 4: smallest box first.  Leaves are tested where they are met (as on the device).  From the
+// root, every shadow ray.  out: [0] rays, [1] occluded rays, [2] block visits of occluded rays, [3] their shape tests,
+// [4] block visits of the others, [5] their shape tests
+extern "C" int sim_anyhit_order(const orc_scene* s, const rt_image_spec* spec, uint64_t seed, int mode, double* out) {
+    const Scene& sc = s->sc;
+    const int W = spec->width, H = spec->height, reps = spec->soft_shadow_monte_carlo_repetitions;
+    const CameraF64 c64 = new_camera(sc, W, H);
+    const Camera<float> cf = narrow_camera<float>(c64);
+    const Tables<float>& T = sc.t32;
+    Node* root = effective(sc.wide_root);
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (root->as_leaf) return 0;
+    struct Cand { Node* e; float key; };
+    auto walk = [&](const Ray<float>& r, float tmin, float tmax, double* visits, double* shapes) {
+        const StackRay sr = make_stack_ray(r);
+        std::vector<Node*> stack;
+        std::vector<int> group;
+        Node* cur = root;
+        for (;;) {
+            *visits += 1;
+            Cand pending[8]; int np = 0;
+            for (int k = 0; k < 8; ++k) {
+                Node* e = cur->slot[k ^ sr.sign];
+                if (!e) continue;
+                float tn = tmin, tf = tmax;
+                for (int a = 0; a < 3; ++a) {
+                    const float lo = (sr.sign >> a) & 1 ? e->fmax[a] : e->fmin[a], hi = (sr.sign >> a) & 1 ? e->fmin[a] : e->fmax[a];
+                    const float t0 = lo * sr.inv[a] - sr.oi[a], t1 = hi * sr.inv[a] - sr.oi[a];
+                    if (t0 == t0) tn = std::max(tn, t0);
+                    if (t1 == t1) tf = std::min(tf, t1);
+                }
+                if (!(tn <= tf)) continue;
+                if (e->as_leaf) {
+                    group.clear();
+                    subtree_shapes(e, &group);
+                    for (int shape : group) {
+                        *shapes += 1;
+                        const Hit<float> sh = T.shapes[(size_t)shape].kind == RT_SHAPE_TRIANGLE ? triangle_occludes_f32(T.shapes[(size_t)shape], shape, r, tmin, tmax)
+                                                                                                : shape_hit(T, shape, r, tmin, tmax);
+                        if (sh.t > 0.0f && sh.t <= tmax) return true;
+                    }
+                    continue;
+                }
+                float key = (float)np;
+                if (mode == 1) key = -(tf - tn);
+                else if (mode == 2) key = tn;
+                else if (mode == 3) key = -(float)e->count;
+                else if (mode == 4) {
+                    const float dx = e->fmax[0] - e->fmin[0], dy = e->fmax[1] - e->fmin[1], dz = e->fmax[2] - e->fmin[2];
+                    key = dx * dy + dy * dz + dz * dx;
+                }
+                pending[np++] = Cand{e, key};
+            }
+            std::stable_sort(pending, pending + np, [](const Cand& a, const Cand& b) { return a.key < b.key; });
+            for (int i = np - 1; i >= 1; --i) stack.push_back(pending[i].e);
+            if (np > 0) { cur = pending[0].e; continue; }
+            if (stack.empty()) return false;
+            cur = stack.back();
+            stack.pop_back();
+        }
+    };
+    for (int row = 0; row < H; ++row)
+        for (int i = 0; i < W; ++i) {
+            const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(row * W + i), 0u};
+            const Ray<float> r = camera_ray(cf, W, H, i, H - 1 - row, key);
+            Hit<float> hit;
+            if (!trace_stack_f32(sc, r, 0.0f, FLT_MAX, false, hit, nullptr)) continue;
+            const Shape<float>& sh = T.shapes[hit.shape];
+            const Material<float>& m = T.materials[sh.material];
+            if (m.kind != RT_MAT_PHONGBLINN) continue;
+            int lpos = -1;
+            for (size_t li = 0; li < T.lights.size(); ++li) {
+                const Light<float>& L = T.lights[li];
+                if (L.kind == RT_LIGHT_AMBIENT) continue;
+                ++lpos;
+                const V3<float> ldir = unit(sub(L.pos, hit.p));
+                const float inten = saturate(dot(hit.normal, ldir));
+                const V3<float> h = unit(add(ldir, r.d));
+                const float si = std::pow(saturate(dot(hit.normal, h)), m.param);
+                if (inten == 0.0f && (si == 0.0f || (m.spec.x == 0 && m.spec.y == 0 && m.spec.z == 0))) continue;
+                for (int k = 0; k < reps; ++k) {
+                    const V3<float> jit = scale(0.25f, random_in_unit_sphere<float>(key, 0, P_SHADOW, (uint32_t)(lpos * reps + k)));
+                    const V3<float> shifted = add(L.pos, jit);
+                    if (L.kind == RT_LIGHT_SPOT && !(dot(L.look_dir, unit(sub(hit.p, shifted))) >= L.cos_angle)) continue;
+                    const V3<float> ld = sub(shifted, hit.p);
+                    const float d = norm(ld);
+                    double v = 0, st = 0;
+                    const bool oc = walk(Ray<float>{hit.p, scale(1.0f / d, ld)}, 0.01f, d, &v, &st);
+                    out[0] += 1;
+                    if (oc) { out[1] += 1; out[2] += v; out[3] += st; } else { out[4] += v; out[5] += st; }
+                }
+            }
+        }
+    return 0;
+}
+
 // ---- sub-beams: the pairs the ball beam does not prove clear, tried again in groups of `group` repetitions ----------
 // A group's beam is the box of ITS jittered light positions (not the whole ball): { p + s (D' + j) }, j within the
 // group's per-axis range.  out: [0] non-clear pairs, [1] their rays, [2] sub-beams walked, [3] clear sub-beams,
