@@ -286,3 +286,43 @@ def test_pair_beams_on_random_scenes(backend, rt, monkeypatch):
         assert st.rays_continuation > 0 and st0.rays_shadow_beam == 0
         total_beam += st.rays_shadow_beam
     assert total_beam > 0
+
+
+def test_two_host_threads_create_and_render_at_once(backend, rt, c1):
+    """The library's process-wide state (the runtime warm-up that the first rt_init of a device starts, the static
+    workspace's address, the thread-local error text) under two callers at once: each thread creates its own scene of
+    the reference's example and renders it — ctypes releases the GIL for the calls — and both get the bytes of a frame
+    rendered alone; a failing call on one thread leaves its text on that thread only."""
+    import threading
+    spec, scene = c1
+    spec = copy.copy(spec)
+    spec.Width, spec.Height, spec.AntiAliasingFactor = 160, 96, 4
+    with backend.DeviceScene(scene) as dev:
+        alone, _ = dev.render(spec)
+    frames, errors = {}, {}
+    start = threading.Barrier(2)
+
+    def work(i):
+        try:
+            start.wait(timeout=60)
+            for _ in range(2):
+                with backend.DeviceScene(scene) as dev:
+                    frames[i], _ = dev.render(spec)
+            if i == 1:  # an error on this thread: the other thread's calls go on
+                bad = copy.copy(spec)
+                bad.BvhTraversalAlgorithm = 7
+                with backend.DeviceScene(scene) as dev:
+                    with pytest.raises(Exception, match="No trace algorithm found for 7"):
+                        dev.render(bad)
+        except BaseException as e:  # noqa: BLE001 - reported by the main thread
+            errors[i] = e
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=170)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads)
+    for i in range(2):
+        assert np.array_equal(frames[i], alone), i
