@@ -177,7 +177,10 @@ __device__ __forceinline__ uint32_t xcd_block() {
 
 // The queue lengths live in Wk.counters: the host launches on an upper bound (the previous bounce's length) and
 // every kernel reads the real one, so no launch waits for a read-back.
-__global__ __launch_bounds__(kBlock) void k_extend(DScene S, Work Wk, const uint32_t* queue, const uint32_t* n_ptr) {
+#ifndef RTGO_EXTEND_WAVES
+#define RTGO_EXTEND_WAVES 6  // frame ms at config 3: 4 waves (104 VGPRs, the compiler's own choice) 305.2-306.1, 5 (88) 303.4-303.7, 6 (80, 36 B scratch) 302.3-303.4, 7 (72) 304.3
+#endif
+__global__ __launch_bounds__(kBlock, RTGO_EXTEND_WAVES) void k_extend(DScene S, Work Wk, const uint32_t* queue, const uint32_t* n_ptr) {
     __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
     const uint32_t n = *n_ptr;
     // (plain block order here: with xcd_block() the XCDs get image regions of unequal cost, 12.1 -> 15.9 ms per frame)
@@ -396,7 +399,10 @@ __global__ __launch_bounds__(kBlock) void k_pair_compact(Work Wk, const uint32_t
 // Beam).  A pair whose beam meets no leaf box, and that lies inside the spot cone for every jittered light position, has
 // all `reps` repetitions visible: its count is written here and none of its rays is generated.  The other pairs go on
 // to k_shadow through a second queue (the space of pair_seg, which k_pair_compact has consumed).
-__global__ __launch_bounds__(kBlock) void k_pair_beam(DScene S, Batch B, Work Wk, const uint32_t* n_hits_ptr, const uint32_t* pair_counter) {
+#ifndef RTGO_BEAM_WAVES
+#define RTGO_BEAM_WAVES 7  // frame ms at config 3: 5 waves (86 VGPRs, the compiler's own choice) 308-310, 6 (78) 307.5, 7 (72) 303.5-304.2; the block's 20.5 KB of LDS allow no 8th
+#endif
+__global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S, Batch B, Work Wk, const uint32_t* n_hits_ptr, const uint32_t* pair_counter) {
     __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
     const uint32_t n_hits = *n_hits_ptr;
     const uint32_t n_pairs = *pair_counter;
