@@ -170,6 +170,11 @@ const char* rt_last_error(void);
  * tree build to hide behind; rt_scene_create waits for that thread before its first upload. */
 int rt_init(int device);
 
+/* What the loaded library was built from: "src=<hash of its sources> shadow_waves=7 lds_stack=11 ..." (the compile-time
+ * knobs of the kernels).  No counterpart in the reference; bench.py uses it to tell whether committed profile counts
+ * belong to this build. */
+const char* rt_build_info(void);
+
 /* Replaces NewBoundingVolumeHierarchy(&scene.Shapes) (accelerationstructures.go:27-65,
  * called at raytracer.go:69) + NewCamera (camera.go:18-35, raytracer.go:59-68):
  * builds the acceleration structure on the host, flattens it to child-record / primitive arrays and
@@ -247,6 +252,17 @@ int rt_multi_create(const rt_scene_desc* desc, const int32_t* devices, int32_t n
 void rt_multi_destroy(rt_multi* multi);
 int rt_multi_render(rt_multi* multi, const rt_image_spec* spec, int32_t mode, uint64_t seed,
                     uint8_t* rgba_out, rt_stats* stats);
+/* A share that fails (allocation, launch) makes the whole call fail: every share's host thread is joined first, and
+ * only when all of them rendered is the reduce enqueued (all ranks inside one ncclGroupStart/End), so no rank is left
+ * waiting in a collective; on failure every device is synchronised before the first error is returned. */
+typedef struct rt_multi_info {
+    int32_t n_shares;            /* entries of `devices` in rt_multi_create                                   */
+    int32_t n_distinct_devices;
+    int32_t rccl_ranks;          /* communicators ncclCommInitAll made: n_shares when they are >= 2 distinct  */
+                                 /* devices, 0 when the shares are summed on one device without RCCL          */
+    int32_t _pad;
+} rt_multi_info;
+int rt_multi_get_info(const rt_multi* multi, rt_multi_info* out);
 /* one shot: create + render + destroy */
 int rt_generate_image_multi(const rt_scene_desc* desc, const rt_image_spec* spec, const int32_t* devices,
                             int32_t n_devices, int32_t mode, uint64_t seed, uint8_t* rgba_out, rt_stats* stats);

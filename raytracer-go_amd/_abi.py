@@ -89,6 +89,10 @@ class RtShare(C.Structure):
                 ("n_tiles", C.c_int64)]
 
 
+class RtMultiInfo(C.Structure):
+    _fields_ = [("n_shares", C.c_int32), ("n_distinct_devices", C.c_int32), ("rccl_ranks", C.c_int32), ("_pad", C.c_int32)]
+
+
 class RtSceneInfo(C.Structure):
     _fields_ = [("n_shapes", C.c_int64), ("n_inner_nodes", C.c_int64),
                 ("n_child_records", C.c_int64), ("tree_depth", C.c_int32),

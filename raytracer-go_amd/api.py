@@ -219,6 +219,8 @@ class TriangleMesh:
         """The mesh as rt_shape records (into `out`, a slice of the scene's table, when given)."""
         n = len(self)
         rec = np.empty(n, dtype=_abi.SHAPE_DTYPE) if out is None else out
+        if n == 0:  # an empty STL / mesh: no records (a reshape(0, -1) cannot infer its width)
+            return rec
         # a record is 4 int32 {kind, material, single_sided, pad} and 9 doubles {a, b, c}: one strided copy each
         rec.view(np.int32).reshape(n, -1)[:, :4] = (_abi.RT_SHAPE_TRIANGLE, material_index, 1 if self.SingleSided else 0, 0)
         rec.view(np.float64).reshape(n, -1)[:, 2:] = self.vertices.reshape(n, 9)

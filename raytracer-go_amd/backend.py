@@ -17,7 +17,7 @@ SYMBOLS = ("rt_last_error", "rt_init", "rt_scene_create", "rt_scene_destroy", "r
            "rt_render", "rt_render_accum_device", "rt_render_accum", "rt_resolve_device",
            "rt_generate_image", "rt_trace_rays", "rt_camera_rays", "rt_scatter_probe",
            "rt_render_accum_device_static", "rt_multi_create", "rt_multi_destroy", "rt_multi_render", "rt_generate_image_multi",
-           "rt_partition_share")
+           "rt_partition_share", "rt_multi_get_info", "rt_build_info")
 
 
 class RtgoError(RuntimeError):
@@ -67,6 +67,8 @@ def lib():
         L.rt_multi_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]
         L.rt_generate_image_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]
         L.rt_scatter_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.rt_multi_get_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.rt_build_info.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -78,6 +80,11 @@ def _check(rc):
 
 def init(device=0):
     _check(lib().rt_init(device))
+
+
+def build_info():
+    """The loaded library's source hash and kernel knobs (rt_build_info) as a dict of strings."""
+    return dict(kv.split("=", 1) for kv in lib().rt_build_info().decode().split())
 
 
 class DeviceScene:
@@ -212,9 +219,15 @@ class MultiDeviceScene:
         except Exception:
             pass
 
-    def render(self, spec, mode=_abi.RT_PART_TILES, seed=0x5EED):
+    def info(self):
+        i = _abi.RtMultiInfo()
+        _check(lib().rt_multi_get_info(self._h, C.addressof(i)))
+        return {n: getattr(i, n) for n, _ in i._fields_ if not n.startswith("_")}
+
+    def render(self, spec, mode=_abi.RT_PART_TILES, seed=0x5EED, out=None):
         s = _abi.image_spec(spec)
-        out = np.zeros((spec.Height, spec.Width, 4), dtype=np.uint8)
+        if out is None:
+            out = np.zeros((spec.Height, spec.Width, 4), dtype=np.uint8)
         st = _abi.RtStats()
         _check(lib().rt_multi_render(self._h, C.addressof(s), mode, seed, out.ctypes.data, C.addressof(st)))
         return out, st

@@ -1808,6 +1808,8 @@ struct Rccl {
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static int load_rccl(Rccl* r) {
@@ -1819,8 +1821,11 @@ static int load_rccl(Rccl* r) {
     r->CommInitAll = (decltype(r->CommInitAll))dlsym(r->handle, "ncclCommInitAll");
     r->CommDestroy = (decltype(r->CommDestroy))dlsym(r->handle, "ncclCommDestroy");
     r->Reduce = (decltype(r->Reduce))dlsym(r->handle, "ncclReduce");
+    r->GroupStart = (decltype(r->GroupStart))dlsym(r->handle, "ncclGroupStart");
+    r->GroupEnd = (decltype(r->GroupEnd))dlsym(r->handle, "ncclGroupEnd");
     r->GetErrorString = (decltype(r->GetErrorString))dlsym(r->handle, "ncclGetErrorString");
-    if (!r->CommInitAll || !r->CommDestroy || !r->Reduce || !r->GetErrorString) return fail(RT_ERR_DEVICE, "librccl lacks ncclCommInitAll / ncclReduce");
+    if (!r->CommInitAll || !r->CommDestroy || !r->Reduce || !r->GroupStart || !r->GroupEnd || !r->GetErrorString)
+        return fail(RT_ERR_DEVICE, "librccl lacks ncclCommInitAll / ncclReduce / ncclGroupStart / ncclGroupEnd");
     return RT_OK;
 }
 
@@ -1901,24 +1906,48 @@ static int rt_multi_render_impl(rt_multi* m, const rt_image_spec* spec, int32_t 
     if (mode != RT_PART_TILES && mode != RT_PART_SAMPLES) return fail(RT_ERR_INVALID, "mode must be RT_PART_TILES or RT_PART_SAMPLES");
     const size_t count = (size_t)spec->width * spec->height * 3;
     std::vector<rt_stats> st((size_t)n);
+    // RTGO_FAIL_SHARE=r: share r fails before it renders (test hook for the error path below)
+    const char* fail_env = std::getenv("RTGO_FAIL_SHARE");
+    const int fail_share = fail_env ? std::atoi(fail_env) : -1;
+    // Phase 1: every share renders into its own device's accumulation buffer.  on_every_rank() joins all the
+    // threads, so every share has either finished its frame (a call with stats blocks until then) or failed
+    // before anything below touches a collective.
     rc = on_every_rank(n, [&](int r) {
         rt_scene* s = m->scenes[(size_t)r];
         hipStream_t stream = m->streams[(size_t)r];
         HIP_TRY(hipSetDevice(s->device));
+        if (r == fail_share) return fail(RT_ERR_DEVICE, "injected failure (RTGO_FAIL_SHARE)");
         HIP_TRY(s->accum.ensure(count * sizeof(float)));
         HIP_TRY(hipMemsetAsync(s->accum.p, 0, count * sizeof(float), stream));
         rt_partition part{};
         part.seed = seed; part.mode = mode; part.rank = r; part.world_size = n;
-        int c = rt_render_accum_device(s, spec, &part, (float*)s->accum.p, stream, &st[(size_t)r]);
-        if (c != RT_OK) return c;
-        if (!m->comms.empty()) {  // RCCL over xGMI: the shares summed onto the first device, in place there
-            const ncclResult_t e = m->rccl.Reduce(s->accum.p, s->accum.p, count, ncclFloat, ncclSum, 0, m->comms[(size_t)r], stream);
-            if (e != ncclSuccess) return fail(RT_ERR_DEVICE, std::string("ncclReduce: ") + m->rccl.GetErrorString(e));
-        }
-        HIP_TRY(hipStreamSynchronize(stream));
-        return RT_OK;
+        return rt_render_accum_device(s, spec, &part, (float*)s->accum.p, stream, &st[(size_t)r]);
     });
-    if (rc != RT_OK) return rc;
+    if (rc != RT_OK) {
+        // A share failed: no rank enters the reduce (a rank alone in a collective would wait for ever), and
+        // nothing of the frame is left running on any device when the error comes back.
+        const std::string msg = g_err;
+        for (int r = 0; r < n; ++r)
+            if (hipSetDevice(m->scenes[(size_t)r]->device) == hipSuccess) (void)hipDeviceSynchronize();
+        return fail(rc, msg);
+    }
+    // Phase 2, only when every share succeeded: RCCL over xGMI, the shares summed onto the first device, in place
+    // there.  One host thread enqueues all ranks' ncclReduce inside one group (the single-process form of the
+    // collective: nothing is launched until ncclGroupEnd has every rank's call, so a rank cannot be left alone in it).
+    if (!m->comms.empty()) {
+        ncclResult_t e = m->rccl.GroupStart();
+        for (int r = 0; r < n && e == ncclSuccess; ++r) {
+            rt_scene* s = m->scenes[(size_t)r];
+            e = m->rccl.Reduce(s->accum.p, s->accum.p, count, ncclFloat, ncclSum, 0, m->comms[(size_t)r], m->streams[(size_t)r]);
+        }
+        const ncclResult_t e2 = m->rccl.GroupEnd();
+        if (e == ncclSuccess) e = e2;
+        if (e != ncclSuccess) return fail(RT_ERR_DEVICE, std::string("ncclReduce: ") + m->rccl.GetErrorString(e));
+        for (int r = 0; r < n; ++r) {
+            HIP_TRY(hipSetDevice(m->scenes[(size_t)r]->device));
+            HIP_TRY(hipStreamSynchronize(m->streams[(size_t)r]));
+        }
+    }
     rt_scene* root = m->scenes[0];
     HIP_TRY(hipSetDevice(root->device));
     if (m->comms.empty())  // shares that live on the root's own device (a device listed more than once): summed there
@@ -1943,6 +1972,33 @@ static int rt_multi_render_impl(rt_multi* m, const rt_image_spec* spec, int32_t 
         *stats = t;
     }
     return RT_OK;
+}
+
+int rt_multi_get_info(const rt_multi* m, rt_multi_info* out) {
+    if (!m || !out) return fail(RT_ERR_INVALID, "multi/out is NULL");
+    rt_multi_info i{};
+    i.n_shares = (int32_t)m->scenes.size();
+    for (size_t a = 0; a < m->devices.size(); ++a) {
+        bool seen = false;
+        for (size_t b = 0; b < a; ++b) seen = seen || m->devices[b] == m->devices[a];
+        if (!seen) ++i.n_distinct_devices;
+    }
+    for (ncclComm_t c : m->comms) if (c) ++i.rccl_ranks;
+    *out = i;
+    return RT_OK;
+}
+
+// What this library was built from: a hash of its sources (csrc/Makefile) and the compile-time knobs of its kernels.
+// bench.py compares it with the build that profiles/*/bounds.json was counted on.
+#ifndef RTGO_SRC_HASH
+#define RTGO_SRC_HASH "unknown"
+#endif
+#define RTGO_STR2(x) #x
+#define RTGO_STR(x) RTGO_STR2(x)
+const char* rt_build_info(void) {
+    return "src=" RTGO_SRC_HASH " shadow_waves=" RTGO_STR(RTGO_SHADOW_WAVES) " beam_waves=" RTGO_STR(RTGO_BEAM_WAVES)
+           " extend_waves=" RTGO_STR(RTGO_EXTEND_WAVES) " lds_stack=" RTGO_STR(RTGO_LDS_STACK) " pend_cap=" RTGO_STR(RTGO_PEND_CAP)
+           " flush_lanes=" RTGO_STR(RTGO_FLUSH_LANES) " visit_batch=" RTGO_STR(RTGO_VISIT_BATCH) " max_grid=" RTGO_STR(RTGO_MAX_GRID);
 }
 
 #ifdef RTGO_PROF

@@ -1,0 +1,128 @@
+"""Round-3 cases (VERDICT r02 "Next round" 1, 5, 6, 7): the multi-GPU call's error path, bench.py's launchers, a
+scene far from the origin against the reference-faithful float64 traversal, the RMSE gate of the headline config."""
+import copy
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_multi_share_failure_returns_an_error(backend, rt, c1, monkeypatch):
+    """A share that fails must fail the whole rt_multi_render call — no rank may be left waiting in the reduce
+    (the RCCL route hung when one share returned before ncclReduce).  The shares render first, all host
+    threads are joined, and only then is the collective enqueued; here share 1 of 3 is made to fail."""
+    spec, scene = copy.copy(c1[0]), c1[1]
+    spec.Width, spec.Height, spec.AntiAliasingFactor = 160, 95, 2
+    abi = rt._abi
+    with backend.MultiDeviceScene(scene, [0, 0, 0]) as m:
+        info = m.info()
+        assert info == {"n_shares": 3, "n_distinct_devices": 1, "rccl_ranks": 0}
+        good, st = m.render(spec, mode=abi.RT_PART_TILES)
+        monkeypatch.setenv("RTGO_FAIL_SHARE", "1")
+        with pytest.raises(backend.RtgoError) as e:
+            m.render(spec, mode=abi.RT_PART_TILES)
+        assert e.value.code == abi.RT_ERR_DEVICE and "share 1" in str(e.value) and "injected" in str(e.value)
+        monkeypatch.delenv("RTGO_FAIL_SHARE")
+        again, st2 = m.render(spec, mode=abi.RT_PART_TILES)  # the handle is still usable, and the frame is the same
+        assert (again == good).all() and st2.rays == st.rays
+
+
+def _bench(*args):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", *args], capture_output=True, text=True, timeout=300)
+    return p
+
+
+def test_bench_launchers_agree_on_one_gpu():
+    """`python bench.py --gpus N` needs no outside launcher: without WORLD_SIZE it drives rt_multi_* in-process.  At
+    N = 1 that path and the single-device path must report the same rays and, within noise, the same frame time."""
+    common = ("--gpus", "1", "--width", "640", "--height", "360", "--spp", "16", "--steps", "3", "--warmup", "1")
+    a = _bench(*common)
+    b = _bench(*common, "--launcher", "rt_multi")
+    assert a.returncode == 0, a.stderr[-2000:]
+    assert b.returncode == 0, b.stderr[-2000:]
+    ja, jb = json.loads(a.stdout.strip().splitlines()[-1]), json.loads(b.stdout.strip().splitlines()[-1])
+    assert ja["launcher"] == "single" and jb["launcher"] == "rt_multi" and jb["rccl_ranks"] == 0
+    assert ja["rays_per_frame"] == jb["rays_per_frame"]
+    assert ja["n_gpus"] == jb["n_gpus"] == 1
+    # value counts traversals launched; the rays a beam walk settled are only in value_rays_decided
+    for j in (ja, jb):
+        rp = j["rays_per_frame"]
+        launched = rp["primary"] + rp["continuation"] + rp["shadow"] - rp["of_which_decided_by_pair_beams"]
+        assert abs(j["value"] * 1e6 * j["sec_per_frame"] - launched) <= 1e-6 * launched
+        assert j["value_rays_decided"] >= j["value"]
+    print("single", ja["ms_per_step"], "rt_multi", jb["ms_per_step"])
+    assert abs(ja["ms_per_step"] - jb["ms_per_step"]) <= 0.15 * ja["ms_per_step"] + 1.0  # + the 0.9 MB frame's copy to the host
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """Fewer visible devices than --gpus: a message and a non-zero exit, never shares that double up on a device."""
+    p = _bench("--gpus", "64", "--steps", "1")
+    assert p.returncode != 0 and "visible" in p.stderr and not p.stdout.strip()
+    env = dict(os.environ, WORLD_SIZE="64", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0 and "visible" in p.stderr and not p.stdout.strip()
+
+
+def test_bench_tile_mode_config5_small():
+    """`--config 5 --mode tiles`: the other partition north_star names, through the same command."""
+    p = _bench("--gpus", "1", "--config", "5", "--mode", "tiles", "--width", "640", "--height", "360", "--spp", "4", "--steps", "1", "--warmup", "0")
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads(p.stdout.strip().splitlines()[-1])
+    assert j["config"]["workload"].startswith("config5") and j["rays_per_frame"]["continuation"] > 0
+    assert j["roofline"]["stale"] is True and j["roofline"]["frac"] is None  # the committed counts are the headline workload's
+
+
+@pytest.mark.parametrize("offset", [(1e3, -5e2, 2.5e2), (1e4, 1e4, -1e4)])
+def test_translated_scene_against_float64_reference(backend, bridge, scenes, rt, offset):
+    """ADVICE r01-3 / VERDICT r02 weak 1b: the device's slab test is fma(box, 1/d, -(o/d)) with o/d rounded first,
+    which loses bits when |o| >> the box (accelerationstructures.go:356-417 subtracts before it divides).  Config 2's
+    mesh moved far from the origin, 60,000 camera rays: shape ids against the float64 best-first traversal."""
+    spec, scene = scenes.config2(160, 90, 2, 4)
+    off = rt.Vec(*offset)
+    for s in scene.Shapes:
+        s.Translate(off)
+    for l in scene.Lights:
+        if hasattr(l, "Position"):
+            l.Position = rt.Vec(l.Position.X + off.X, l.Position.Y + off.Y, l.Position.Z + off.Z)
+    for name in ("CameraLookFrom", "CameraLookAt", "CameraFocusPoint"):
+        v = getattr(scene, name)
+        setattr(scene, name, rt.Vec(v.X + off.X, v.Y + off.Y, v.Z + off.Z))
+    n_rays = 60000
+    rng = np.random.default_rng(9)
+    px = np.stack([rng.integers(0, spec.Width, n_rays), rng.integers(0, spec.Height, n_rays),
+                   rng.integers(0, spec.AntiAliasingFactor, n_rays)], 1).astype(np.int32)
+    with backend.DeviceScene(scene) as dev, bridge.OracleScene(scene) as osc:
+        rays = np.zeros((n_rays, 8), np.float32)
+        rays[:, :6] = dev.camera_rays(spec, px)
+        ids, t = dev.trace_rays(rays)
+        # the SAME float32 rays through the float64 traversal: what differs is the traversal's arithmetic alone
+        ids64, t64 = osc.trace_rays(rays.astype(np.float64), mode=bridge.F64_DIJKSTRA)
+        # shadow-style any-hit rays from the hit points towards the light: the quantised walk, same comparison
+        hit = ids >= 0
+        p = rays[hit, :3] + t[hit, None] * rays[hit, 3:6]
+        lp = np.array([l.Position.X for l in scene.Lights if hasattr(l, "Position")][:1] + [l.Position.Y for l in scene.Lights if hasattr(l, "Position")][:1]
+                      + [l.Position.Z for l in scene.Lights if hasattr(l, "Position")][:1], np.float32)
+        d = lp[None, :] - p
+        dist = np.linalg.norm(d, axis=1).astype(np.float32)
+        sh = np.zeros((hit.sum(), 8), np.float32)
+        sh[:, :3], sh[:, 3:6], sh[:, 6], sh[:, 7] = p, d / dist[:, None], 0.01, dist
+        occ, _ = dev.trace_rays(sh, any_hit=True)
+        # doesReachLight (light.go:141-160): nearest hit from tMin = 0.01, occluded iff it lies before the light
+        near64, tn64 = osc.trace_rays(sh.astype(np.float64), mode=bridge.F64_DIJKSTRA)
+        occ64 = ((near64 >= 0) & (tn64 <= sh[:, 7])).astype(np.int32)
+    differ = ids != ids64
+    miss_lost = (ids < 0) & (ids64 >= 0)   # the failure a too-tight slab test produces: a hit the device walks past
+    occ_differ = occ != occ64
+    print(f"offset {offset}: shape ids differ on {differ.sum()} of {n_rays} rays ({miss_lost.sum()} lost hits); "
+          f"any-hit differs on {occ_differ.sum()} of {occ.size} ({((occ == 0) & (occ64 == 1)).sum()} lost occluders)")
+    scale = max(abs(x) for x in offset)
+    # float32 spacing at the offset (6e-5 at 1e3, 1e-3 at 1e4) against triangles of ~0.02: silhouette rays flip
+    limit = 2e-4 if scale <= 1e3 else 3e-3
+    assert differ.mean() <= limit, differ.mean()
+    assert occ_differ.mean() <= 10 * limit, occ_differ.mean()

@@ -52,6 +52,40 @@ def test_flatten_example_scene(rt, c1):
     assert flat._lights[1].kind == rt._abi.RT_LIGHT_SPOT and flat._lights[1].angle_deg == 30
 
 
+def test_empty_mesh_flattens_to_no_records(rt, c1):
+    """A mesh of zero triangles (an empty STL) adds nothing to the shape table."""
+    spec, scene = c1
+    empty = rt.TriangleMesh(np.zeros((0, 3, 3)), False, scene.Shapes[0].Mat)
+    assert len(empty.to_records(0)) == 0
+    sc = rt.Scene(scene.CameraLookFrom, scene.CameraLookAt, scene.CameraUp, scene.CameraFocusPoint, scene.CameraAperature,
+                  scene.CameraFov, [scene.Shapes[0], empty, scene.Shapes[5]], scene.Lights)
+    flat = rt._abi.FlatScene(sc)
+    assert flat.desc.n_shapes == 2 and list(flat.shapes["kind"]) == [1, 2]
+
+
+def test_build_info_names_the_sources_and_knobs(backend):
+    """rt_build_info: what bench.py compares with the build profiles/*/bounds.json was counted on."""
+    backend.build()
+    info = backend.build_info()
+    assert set(info) >= {"src", "shadow_waves", "beam_waves", "extend_waves", "lds_stack", "pend_cap"}
+    assert re.fullmatch(r"[0-9a-f]{12}", info["src"]) and int(info["shadow_waves"]) >= 1
+
+
+def test_bench_without_a_gpu_exits_with_a_message():
+    """bench.py --gpus N, with or without an outside launcher: no device, no line (and never a CPU fallback)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env_extra in ({}, {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env.update(env_extra)
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, env=env, timeout=600)
+        assert p.returncode != 0 and "MI355X" in p.stderr and not p.stdout.strip()
+
+
 def test_shape_transforms(rt):
     """shape.go:80-89,165-181,240-263: Z then X then Y rotation in degrees; Sphere.Rotate is a no-op,
     Sphere.Scale scales the radius only."""
