@@ -10,7 +10,8 @@ import numpy as np
 from . import _abi
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "librtgo_hip.so")
+# RTGO_LIB: another build of the same library (A/B runs of compile-time knobs: scripts/sweep_variants.sh)
+LIB_PATH = os.environ.get("RTGO_LIB") or os.path.join(_CSRC, "librtgo_hip.so")
 
 # every extern "C" symbol include/rtgo.h declares
 SYMBOLS = ("rt_last_error", "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_scene_get_info",

@@ -459,6 +459,7 @@ __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S,
 #ifndef RTGO_SHADOW_WAVES
 #define RTGO_SHADOW_WAVES 7  // k_shadow ms per frame at config 3 (quantised walk): 5 waves (LDS stack 20) 416, 6 (15) 395, 7 (11) 392, 8 (8) 404; with pair beams (hard rays only): 6 (15) 299.4, 6 (13) 300.6, 7 (11) 293.1, 7 (10) 293.5
 #endif
+template <bool MANY_REPS>  // more than 64 repetitions: a lane runs several of a pair's rays, one after the other
 __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, Batch B, Work Wk, const uint32_t* n_hits_ptr, int bounce,
                                                    int group, int group_shift, const uint32_t* pairs, const uint32_t* pair_counter, const uint32_t* beam_state) {
     __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
@@ -467,33 +468,37 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
     const uint32_t gtid = xcd_block() * kBlock + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlock;
     const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride, s_wave + (threadIdx.x >> 6) * 128};
-    const unsigned long long total = (unsigned long long)(*pair_counter) * group;  // written by k_pair_offsets, same stream
-    const unsigned long long rounds = (total + gstride - 1) / gstride;
+    // Little besides the ray itself may stay live across the walk (7 waves per SIMD leave 72 registers, and what does not
+    // fit goes to scratch memory once per round: 44 bytes per ray, 89 GB of writes per frame at config 3, before this
+    // loop kept its state in 32-bit and wave-uniform values and looked the pair up again after the walk).
+    const uint32_t n_pairs = *pair_counter;  // written by k_pair_offsets / k_pair_beam, same stream
+    const uint32_t pairs_per_round = gstride >> group_shift;  // the grid's threads are a multiple of 256, a group is at most 64
+    const uint32_t rounds = (n_pairs + pairs_per_round - 1) / pairs_per_round;
+    const uint32_t my_pair = gtid >> group_shift;
+    const uint32_t r = gtid & (uint32_t)(group - 1);  // the same in every round: the stride is a multiple of the group
+    const unsigned long long low_mask = group == 64 ? ~0ull : ((1ull << group) - 1ull);
     const int lane = (int)__lane_id();
-    const int gbase = lane & ~(group - 1);
-    const unsigned long long gmask = group == 64 ? ~0ull : (((1ull << group) - 1ull) << gbase);
-    unsigned long long launched = 0;
-    for (unsigned long long it = 0; it < rounds; ++it) {
+    unsigned long long launched = 0;  // wave-uniform
+    const int iters = MANY_REPS ? (B.reps + group - 1) >> group_shift : 1;  // > 1 only when reps > 64
+    for (uint32_t it = 0; it < rounds; ++it) {
         // interleaved, not a contiguous range per block: ranges differ too much in cost (1024 blocks: 1760 vs 708 ms)
-        const unsigned long long idx = it * gstride + gtid;
-        const bool active = idx < total;
-        // the pair queue is light-major: the lane groups of a wavefront are consecutive hits (neighbouring
-        // pixels / samples) towards the SAME light, so all 64 shadow rays are nearly parallel
-        const uint32_t r = (uint32_t)(idx & (unsigned long long)(group - 1));
-        const uint32_t hl = active ? pairs[idx >> group_shift] : 0u;
-        const uint32_t lp = hl / n_hits;
-        const uint32_t hit_i = hl - lp * n_hits;
+        const uint32_t pi = it * pairs_per_round + my_pair;  // (plan_render keeps n_pairs + a round of pairs below 2^32)
+        const bool active = pi < n_pairs;
         uint32_t count = 0;
-        const int iters = (B.reps + group - 1) >> group_shift;  // > 1 only when reps > 64
         for (int itn = 0; itn < iters; ++itn) {
             // every lane of the wavefront runs the same number of rounds so the ballot is convergent
             const uint32_t rep = r + (uint32_t)itn * (uint32_t)group;
-            bool vis = false, traced = false;
+            bool traced = false;
             f3 p = mk3(0.0f, 0.0f, 0.0f), dir = mk3(1.0f, 1.0f, 1.0f);
             float dist = 0.0f;
             if (active && rep < (uint32_t)B.reps) {
-                // everything about the ray is derived here, so nothing but (hit, light, rep) stays live
-                // across the traversal below
+                // everything about the ray is derived here, so nothing but the pair's index stays live
+                // across the traversal below.  The pair queue is light-major: the lane groups of a wavefront are
+                // consecutive hits (neighbouring pixels / samples) towards the SAME light, so all 64 shadow rays
+                // are nearly parallel
+                const uint32_t hl = pairs[pi];
+                const uint32_t lp = hl / n_hits;
+                const uint32_t hit_i = hl - lp * n_hits;
                 const uint32_t slot = Wk.phong_queue[hit_i];
                 const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
                 p = add3(mk3(ro.x, ro.y, ro.z), scale3(ro.w, mk3(rdv.x, rdv.y, rdv.z)));
@@ -509,24 +514,34 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
                 if (L.kind == RT_LIGHT_SPOT)  // light.go:126-130 as cos(angle) >= cos(Angle)
                     in_cone = dot3(ld3(L.look_dir), unit3(sub3(p, shifted))) >= L.cos_angle;
                 if (in_cone) {
-                    ++launched;
                     traced = true;
                     const f3 ld = sub3(shifted, p);  // doesReachLight, light.go:141-160
                     dist = norm3(ld);
                     dir = scale3(1.0f / dist, ld);
                 }
             }
+            launched += (unsigned long long)__popcll(__ballot(traced));
             RT_PROF_POINT(2);  // shadow-ray rounds
             // all 64 lanes call: lanes without a ray of their own test shapes for the others
-            const bool occ = occluded<true>(S, st, traced, p, dir, 0.01f, dist, beam_state ? beam_state + (size_t)(idx >> group_shift) * kResumeWords : nullptr);
-            vis = traced && !occ;
-            const unsigned long long m = __ballot(vis);
-            count += (uint32_t)__popcll(m & gmask);
+            const bool occ = occluded<true>(S, st, traced, p, dir, 0.01f, dist, beam_state ? beam_state + (size_t)pi * kResumeWords : nullptr);
+            // the visible repetitions of a (hit, light) counted over its lane group: an integer, no summation order
+            const unsigned long long m = __ballot(traced && !occ);
+            count += (uint32_t)__popcll((m >> (lane & ~(group - 1))) & low_mask);
         }
-        if (active && r == 0) Wk.vis[(size_t)hit_i * S.n_pos_lights + lp] = count;
+        if (r == 0) {
+            // the pair is looked up again (from the lane's constant and the round, not from `pi`, which the compiler
+            // would otherwise keep in scratch memory across the walk, address and all)
+            uint32_t mine = my_pair;
+            asm volatile("" : "+v"(mine));
+            const uint32_t pj = it * pairs_per_round + mine;
+            if (pj < n_pairs) {
+                const uint32_t hl = pairs[pj];
+                const uint32_t lp = hl / n_hits;
+                Wk.vis[(size_t)(hl - lp * n_hits) * S.n_pos_lights + lp] = count;
+            }
+        }
     }
     // shadow rays actually traced: one 64-bit atomic per wavefront
-    for (int off = 32; off > 0; off >>= 1) launched += __shfl_down(launched, off);
     if (lane == 0 && launched) atomicAdd(Wk.frame_counters, launched);
 }
 
@@ -1101,7 +1116,39 @@ struct HostScene {
     std::vector<DMaterial> mats;
     std::vector<DLight> lights;
     int n_pos = 0;
+#ifdef RTGO_QF16
+    std::vector<uint32_t> qblocks16;  // the quantised blocks with float16 planes, 32 words each (device_math.hpp visit_qblock)
+#endif
 };
+
+#ifdef RTGO_QF16
+// 0..255 as float16 bits (exact)
+static inline uint32_t half_bits_of_byte(uint32_t v) {
+    if (v == 0) return 0u;
+    int e = 31 - __builtin_clz(v);
+    return ((uint32_t)(e + 15) << 10) | ((v << (10 - e)) & 0x3ffu);
+}
+// FlatTree::qblocks (octree.hpp QBlock: planes as bytes, 20 words) -> 32 words: words 0..7 unchanged, then per axis the
+// lower and the upper planes of slots 0..7 as float16, two slots per word
+static void expand_qblocks(const std::vector<uint32_t>& q, std::vector<uint32_t>* out) {
+    const size_t n = q.size() / kQBlockWords;
+    out->assign(n * 32, 0u);
+    host_chunks((int64_t)n, [&](int64_t b0, int64_t b1) {
+        for (int64_t b = b0; b < b1; ++b) {
+            const uint32_t* w = q.data() + (size_t)b * kQBlockWords;
+            uint32_t* o = out->data() + (size_t)b * 32;
+            for (int i = 0; i < 8; ++i) o[i] = w[i];
+            const uint8_t* qlo = reinterpret_cast<const uint8_t*>(w + 8);
+            const uint8_t* qhi = reinterpret_cast<const uint8_t*>(w + 14);
+            for (int a = 0; a < 3; ++a)
+                for (int k = 0; k < 8; k += 2) {
+                    o[8 + 8 * a + (k >> 1)] = half_bits_of_byte(qlo[8 * a + k]) | (half_bits_of_byte(qlo[8 * a + k + 1]) << 16);
+                    o[12 + 8 * a + (k >> 1)] = half_bits_of_byte(qhi[8 * a + k]) | (half_bits_of_byte(qhi[8 * a + k + 1]) << 16);
+                }
+        }
+    });
+}
+#endif
 
 static int build_host_scene(const rt_scene_desc* desc, HostScene* h, Laps& lap) {
     {
@@ -1186,6 +1233,9 @@ static int build_host_scene(const rt_scene_desc* desc, HostScene* h, Laps& lap) 
         if (l.kind != RT_LIGHT_AMBIENT) ++n_pos;
     }
     h->n_pos = n_pos;
+#ifdef RTGO_QF16
+    expand_qblocks(h->flat.qblocks, &h->qblocks16);
+#endif
     lap("tables");
     return RT_OK;
 }
@@ -1262,8 +1312,13 @@ static int finish_scene(const rt_scene_desc* desc, const HostScene& h, rt_scene*
     HIP_TRY_S(hipMalloc(&s->d_recs, rec_bytes));
     HIP_TRY_S(hipMemset(s->d_recs, 0, rec_bytes));  // the padding record is fetched (and masked out) for trailing absent slots
     if (!h.flat.records.empty()) HIP_TRY_S(hipMemcpy(s->d_recs, h.flat.records.data(), h.flat.records.size() * sizeof(ChildRecord), hipMemcpyHostToDevice));
+#ifdef RTGO_QF16
+    HIP_TRY_S(hipMalloc(&s->d_qblocks, h.qblocks16.size() * sizeof(uint32_t)));
+    HIP_TRY_S(hipMemcpy(s->d_qblocks, h.qblocks16.data(), h.qblocks16.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+#else
     HIP_TRY_S(hipMalloc(&s->d_qblocks, h.flat.qblocks.size() * sizeof(uint32_t)));
     HIP_TRY_S(hipMemcpy(s->d_qblocks, h.flat.qblocks.data(), h.flat.qblocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+#endif
     HIP_TRY_S(hipMalloc(&s->d_prims, h.prim_words * sizeof(float)));
     HIP_TRY_S(hipMemcpy(s->d_prims, h.prims.get(), h.prim_words * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_tprims, h.prim_words * sizeof(float)));
@@ -1422,7 +1477,8 @@ static int plan_render(const rt_scene* s, const rt_image_spec* spec, const rt_pa
     }
     if (max_paths > ((int64_t)1 << 30)) max_paths = (int64_t)1 << 30;
     // a (hit, light) pair travels as one u32: light * hits + hit
-    const int64_t pair_cap = (((int64_t)1 << 32) - 1) / std::max(1, s->d.n_pos_lights);
+    // (k_shadow indexes pairs with 32 bits and may look one grid-stride round past the end: 2^22 threads at most)
+    const int64_t pair_cap = (((int64_t)1 << 32) - 1 - (int64_t)kMaxGridBlocks * kBlock) / std::max(1, s->d.n_pos_lights);
     if (pair_cap < (int64_t)tile * tile) return fail(RT_ERR_LIMIT, "too many positional lights for one tile of paths; use a smaller tile_size");
     if (max_paths > pair_cap) max_paths = pair_cap;
     P->ns_max = (int)std::min<long long>(P->sB - P->sA, std::min<long long>(64, max_paths / ((long long)tile * tile)));
@@ -1529,8 +1585,12 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
                             resume = resume_on ? wk.beam_state : nullptr;
                         }
                         if (staged) ss.a = stamp();  // ms_shadow brackets k_shadow alone
-                        hipLaunchKernelGGL(k_shadow, dim3(grid_for(n_pairs * P.group, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, B, wk, n_phong, b,
-                                           P.group, P.group_shift, queue, queue_len, resume);
+                        if (reps > 64)
+                            hipLaunchKernelGGL(k_shadow<true>, dim3(grid_for(n_pairs * P.group, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, B, wk, n_phong, b,
+                                               P.group, P.group_shift, queue, queue_len, resume);
+                        else
+                            hipLaunchKernelGGL(k_shadow<false>, dim3(grid_for(n_pairs * P.group, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, B, wk, n_phong, b,
+                                               P.group, P.group_shift, queue, queue_len, resume);
                         if (staged) ss.b = stamp();
                     }
                 }
@@ -2005,7 +2065,8 @@ const char* rt_build_info(void) {
 int rt_debug_prof(unsigned long long* out8, int reset) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(rtgo::g_prof), 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemcpyFromSymbol(out8 + 8, HIP_SYMBOL(rtgo::g_prof2), 4 * sizeof(unsigned long long)));  // out8 holds 12
+    HIP_TRY(hipMemcpyFromSymbol(out8 + 8, HIP_SYMBOL(rtgo::g_prof2), 4 * sizeof(unsigned long long)));  // out8 holds 12 + 129
+    HIP_TRY(hipMemcpyFromSymbol(out8 + 12, HIP_SYMBOL(rtgo::g_prof3), (65 + 64) * sizeof(unsigned long long)));
     if (reset) {
         const unsigned long long z[8] = {};
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtgo::g_prof), z, sizeof(z)));

@@ -9,7 +9,7 @@ scenes = importlib.import_module("raytracer-go_amd.scenes")
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1080
 spec, scene = scenes.config3(1920, rows, 64 if rows < 1080 else 16, 16, asset_dir=os.path.join(ROOT, "tests/golden"))
 dev = backend.DeviceScene(scene)
-out = (ctypes.c_ulonglong * 12)()
+out = (ctypes.c_ulonglong * (12 + 129))()
 L = backend.lib()
 acc, st = dev.render_accum(spec)
 L.rt_debug_prof(out, 0)
@@ -24,3 +24,14 @@ it = v[8]
 if it:
     print("shadow-ray walk: %.1f iterations per wave round; per iteration %.1f lanes only hold leaves, %.1f lanes have nothing to do; %.2f shape loops per wave round"
           % (it / rounds, v[9] / it, v[10] / it, v[11] / rounds))
+hw, hi = v[12:12 + 65], v[12 + 65:12 + 129]
+tot = sum(hw)
+if tot:
+    cum = 0
+    print("walk iterations by walking lanes (cumulative share of iterations):")
+    for w in range(65):
+        cum += hw[w]
+        if w % 4 == 0 or w == 64:
+            print("  <= %2d lanes: %.3f" % (w, cum / tot))
+    n = sum(hi)
+    print("wave rounds by iterations:", " ".join("%d:%.3f" % (i, hi[i] / n) for i in range(64) if hi[i] / n >= 0.002))

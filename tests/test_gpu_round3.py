@@ -85,8 +85,17 @@ def test_translated_scene_against_float64_reference(backend, bridge, scenes, rt,
     mesh moved far from the origin, 60,000 camera rays: shape ids against the float64 best-first traversal."""
     spec, scene = scenes.config2(160, 90, 2, 4)
     off = rt.Vec(*offset)
+    f32 = lambda x: float(np.float32(x))
     for s in scene.Shapes:
         s.Translate(off)
+        # both sides get the geometry the device computes on: coordinates narrowed to float32 (rtgo.h), so that what
+        # is compared is the traversal's arithmetic and not the rounding of the vertices at this distance from 0
+        if isinstance(s, rt.TriangleMesh):
+            s.vertices = s.vertices.astype(np.float32).astype(np.float64)
+        else:
+            for n in ("PointA", "PointB", "PointC"):
+                v = getattr(s, n)
+                setattr(s, n, rt.Vec(f32(v.X), f32(v.Y), f32(v.Z)))
     for l in scene.Lights:
         if hasattr(l, "Position"):
             l.Position = rt.Vec(l.Position.X + off.X, l.Position.Y + off.Y, l.Position.Z + off.Z)
@@ -117,12 +126,16 @@ def test_translated_scene_against_float64_reference(backend, bridge, scenes, rt,
         near64, tn64 = osc.trace_rays(sh.astype(np.float64), mode=bridge.F64_DIJKSTRA)
         occ64 = ((near64 >= 0) & (tn64 <= sh[:, 7])).astype(np.int32)
     differ = ids != ids64
-    miss_lost = (ids < 0) & (ids64 >= 0)   # the failure a too-tight slab test produces: a hit the device walks past
+    # the failure a too-tight slab test produces: a hit the device walks past — it then misses, or finds a farther shape
+    both = (ids >= 0) & (ids64 >= 0)
+    lost = ((ids < 0) & (ids64 >= 0)) | (both & differ & (t > t64 * (1 + 1e-3)))
     occ_differ = occ != occ64
-    print(f"offset {offset}: shape ids differ on {differ.sum()} of {n_rays} rays ({miss_lost.sum()} lost hits); "
-          f"any-hit differs on {occ_differ.sum()} of {occ.size} ({((occ == 0) & (occ64 == 1)).sum()} lost occluders)")
+    lost_occ = (occ == 0) & (occ64 == 1)
+    print(f"offset {offset}: shape ids differ on {differ.sum()} of {n_rays} rays ({lost.sum()} of them lost nearer hits); "
+          f"any-hit differs on {occ_differ.sum()} of {occ.size} ({lost_occ.sum()} lost occluders, {((occ == 1) & (occ64 == 0)).sum()} gained)")
     scale = max(abs(x) for x in offset)
-    # float32 spacing at the offset (6e-5 at 1e3, 1e-3 at 1e4) against triangles of ~0.02: silhouette rays flip
-    limit = 2e-4 if scale <= 1e3 else 3e-3
+    # float32 spacing at the offset (6e-5 at 1e3, 1e-3 at 1e4) against triangles of ~0.03: rays within that of an edge flip
+    limit = 2e-4 if scale <= 1e3 else 2e-3
     assert differ.mean() <= limit, differ.mean()
-    assert occ_differ.mean() <= 10 * limit, occ_differ.mean()
+    assert lost.mean() <= limit / 4, lost.mean()
+    assert occ_differ.mean() <= 2 * limit and lost_occ.mean() <= limit, (occ_differ.mean(), lost_occ.mean())
