@@ -207,13 +207,15 @@ int rt_render(rt_scene* scene, const rt_image_spec* spec, const rt_partition* pa
 int rt_render_accum_device(rt_scene* scene, const rt_image_spec* spec, const rt_partition* part,
                            float* d_accum_rgb, void* hip_stream, rt_stats* stats);
 
-/* rt_render_accum_device for callers that cannot allocate device memory (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments,
+/* rt_render_accum_device for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc, processes whose memory is all spoken for).  It has no counterpart in the reference.  Same arguments,
  * same result (bit-identical to rt_render_accum_device with part->max_paths_per_batch = 262144), but the batch
  * workspace — ray state, queues, counters, the traversal-stack spill region — is a 72 MiB static device array
  * that every GPU the library runs on holds until the process ends, instead of memory the scene allocates on
  * demand.  The call makes no hipMalloc / hipFree / hipHostMalloc / hipEventCreate; per-stage times
- * (ms_extend, ms_shadow) are not measured.  Limits (RT_ERR_LIMIT beyond): tile_size^2 <= 262144 paths per batch,
+ * (ms_extend, ms_shadow) are not measured.  It is NOT capturable into a HIP graph: like rt_render_accum_device it
+ * blocks on a host wait per bounce (hipEventSynchronize, queue lengths read back through pinned memory), which a
+ * stream under capture does not allow.  Limits (RT_ERR_LIMIT beyond): tile_size^2 <= 262144 paths per batch,
  * at most 4 positional lights, RayTracingMaxDepth <= 64, a scene whose tree needs at most 54 traversal-stack
  * entries (rt_scene_info.stack_bound + 1).  All calls on one GPU share that GPU's array: two of them that
  * overlap in time (two host threads, two streams) race; successive calls need nothing from each other. */

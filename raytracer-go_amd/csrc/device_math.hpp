@@ -188,6 +188,8 @@ RT_DEV bool prim_occludes(const DScene& S, uint32_t prim, f3 o, f3 d, float tmin
 #ifdef RTGO_PROF
 __device__ unsigned long long g_prof[8];
 __device__ unsigned long long g_prof3[65 + 64];  // shadow-ray walk: [w] iterations with w walking lanes, [65 + i] wave rounds of i iterations (63: or more)
+__device__ unsigned long long g_prof4[64];  // walking lanes summed per iteration index (63: and later)
+__device__ unsigned long long g_prof3[65 + 64];  // shadow-ray walk: [w] iterations with w walking lanes, [65 + i] wave rounds of i iterations (63: or more)
 __device__ unsigned long long g_prof2[4];  // shadow-ray walk: iterations, lanes only holding leaves, idle lanes, shape loops  // [2i] = times a wavefront passed point i, [2i+1] = lanes active there
 #define RT_PROF_POINT(i)                                                          \
     do {                                                                          \
@@ -860,6 +862,9 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
         npend = 0;
     };
 
+#ifdef RTGO_PROF
+    int prof_iters = 0;
+#endif
 #ifdef RTGO_PROF
     int prof_iters = 0;
 #endif

@@ -9,7 +9,7 @@ scenes = importlib.import_module("raytracer-go_amd.scenes")
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1080
 spec, scene = scenes.config3(1920, rows, 64 if rows < 1080 else 16, 16, asset_dir=os.path.join(ROOT, "tests/golden"))
 dev = backend.DeviceScene(scene)
-out = (ctypes.c_ulonglong * (12 + 129))()
+out = (ctypes.c_ulonglong * (12 + 129 + 64))()
 L = backend.lib()
 acc, st = dev.render_accum(spec)
 L.rt_debug_prof(out, 0)
@@ -35,3 +35,10 @@ if tot:
             print("  <= %2d lanes: %.3f" % (w, cum / tot))
     n = sum(hi)
     print("wave rounds by iterations:", " ".join("%d:%.3f" % (i, hi[i] / n) for i in range(64) if hi[i] / n >= 0.002))
+    sw = v[12 + 129:12 + 129 + 64]
+    reach = [sum(hi[i + 1:]) for i in range(64)]  # wave rounds that run iteration index i (0-based): those of more than i iterations
+    print("iteration index: share of all iterations, walking lanes of the waves still going")
+    total_it = sum(reach[:63]) or 1
+    for i in range(0, 63, 3):
+        if reach[i]:
+            print("  it %2d: %.3f of iterations, %.1f lanes walking" % (i, reach[i] / total_it, sw[i] / reach[i]))
