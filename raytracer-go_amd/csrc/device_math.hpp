@@ -189,7 +189,6 @@ RT_DEV bool prim_occludes(const DScene& S, uint32_t prim, f3 o, f3 d, float tmin
 __device__ unsigned long long g_prof[8];
 __device__ unsigned long long g_prof3[65 + 64];  // shadow-ray walk: [w] iterations with w walking lanes, [65 + i] wave rounds of i iterations (63: or more)
 __device__ unsigned long long g_prof4[64];  // walking lanes summed per iteration index (63: and later)
-__device__ unsigned long long g_prof3[65 + 64];  // shadow-ray walk: [w] iterations with w walking lanes, [65 + i] wave rounds of i iterations (63: or more)
 __device__ unsigned long long g_prof2[4];  // shadow-ray walk: iterations, lanes only holding leaves, idle lanes, shape loops  // [2i] = times a wavefront passed point i, [2i+1] = lanes active there
 #define RT_PROF_POINT(i)                                                          \
     do {                                                                          \
@@ -865,22 +864,21 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
 #ifdef RTGO_PROF
     int prof_iters = 0;
 #endif
-#ifdef RTGO_PROF
-    int prof_iters = 0;
-#endif
     for (;;) {
         uint4 h1 = make_uint4(0u, 0u, 0u, 0u);
         uint32_t leaf_mask = 0, inner_mask = 0, present = 0;
 #ifdef RTGO_PROF
         {   // per iteration of the walk: lanes that only hold leaves, lanes with nothing to do
             const unsigned long long hold = __ballot(!walking && npend > 0u), idle = __ballot(!walking && npend == 0u);
-            ++prof_iters;
+            const int n_walk = __popcll(__ballot(walking));
             if (lane == 0) {
-                atomicAdd(&g_prof3[__popcll(__ballot(walking))], 1ull);
+                atomicAdd(&g_prof3[n_walk], 1ull);
+                atomicAdd(&g_prof4[prof_iters < 63 ? prof_iters : 63], (unsigned long long)n_walk);
                 atomicAdd(&g_prof2[0], 1ull);
                 atomicAdd(&g_prof2[1], (unsigned long long)__popcll(hold));
                 atomicAdd(&g_prof2[2], (unsigned long long)__popcll(idle));
             }
+            ++prof_iters;
         }
 #endif
         if (walking) {  // a box that ends before tmin holds no accepted hit

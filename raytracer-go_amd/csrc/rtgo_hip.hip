@@ -2067,8 +2067,7 @@ int rt_debug_prof(unsigned long long* out8, int reset) {
     HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(rtgo::g_prof), 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemcpyFromSymbol(out8 + 8, HIP_SYMBOL(rtgo::g_prof2), 4 * sizeof(unsigned long long)));  // out8 holds 12 + 129 + 64
     HIP_TRY(hipMemcpyFromSymbol(out8 + 12, HIP_SYMBOL(rtgo::g_prof3), (65 + 64) * sizeof(unsigned long long)));
-    HIP_TRY(hipMemcpyFromSymbol(out8 + 12 + 129, HIP_SYMBOL(rtgo::g_prof4), 64 * sizeof(unsigned long long))); + 129
-    HIP_TRY(hipMemcpyFromSymbol(out8 + 12, HIP_SYMBOL(rtgo::g_prof3), (65 + 64) * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyFromSymbol(out8 + 12 + 129, HIP_SYMBOL(rtgo::g_prof4), 64 * sizeof(unsigned long long)));
     if (reset) {
         const unsigned long long z[8] = {};
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtgo::g_prof), z, sizeof(z)));
