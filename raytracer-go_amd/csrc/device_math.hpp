@@ -460,32 +460,13 @@ RT_DEV QRay make_qray(f3 o, f3 d) {
     return r;
 }
 RT_DEV float qbyte(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); }  // v_cvt_f32_ubyteN
-#ifdef RTGO_QF16
-// The planes as float16 (0..255 are exact), 8 quads per block: {origin, exps | present}, {h1}, then per axis the
-// lower and the upper planes of the 8 slots (one quad each, two slots per word).  A plane goes into the slab test
-// through v_fma_mix_f32 (a float16 operand, float32 result): no v_cvt_f32_ubyte per plane, and the near / far planes
-// are picked by which quad is fetched (the direction's sign bit in the address) instead of by 12 selects.
-constexpr int kQBlockQuads = 8;
-typedef _Float16 rt_h2 __attribute__((ext_vector_type(2)));
-RT_DEV float qhalf(uint32_t w, int hi) { const rt_h2 v = __builtin_bit_cast(rt_h2, w); return (float)(hi ? v.y : v.x); }
-RT_DEV uint32_t quad_word(const uint4& q, int i) { return i == 0 ? q.x : (i == 1 ? q.y : (i == 2 ? q.z : q.w)); }
-RT_DEV float qplane(const uint4& q, int slot) { return qhalf(quad_word(q, slot >> 1), slot & 1); }
-#else
 constexpr int kQBlockQuads = 5;
-#endif
 // Slab tests of the 8 slots of block `blk` in SLOT order.  hit: bit per slot whose box the ray meets inside
 // [tmin, tmax]; h1 = {child base | leaf mask << 24, first leaf shape, meta bytes of slots 0..3, 4..7}.
 RT_DEV uint32_t visit_qblock(const DScene& S, uint32_t blk, const QRay& r, float tmin, float tmax, uint4* h1_out, uint32_t* present_out) {
     RT_PROF_POINT(0);  // block visits
     const uint4* q = S.qblocks + kQBlockQuads * (size_t)blk;
-#ifdef RTGO_QF16
-    const uint32_t nx = r.sign & 1u, ny = (r.sign >> 1) & 1u, nz = r.sign >> 2;
-    const uint4 h0 = q[0], h1 = q[1];
-    // the plane the ray enters through is the lower one for a positive direction, the upper one for a negative
-    const uint4 nX = q[2 + nx], fX = q[3 - nx], nY = q[4 + ny], fY = q[5 - ny], nZ = q[6 + nz], fZ = q[7 - nz];
-#else
     const uint4 h0 = q[0], h1 = q[1], qa = q[2], qb = q[3], qc = q[4];
-#endif
     // t = ((origin + q * step) - o) / d = q * (step / d) + (origin / d - o / d)
     const float sx = __uint_as_float((h0.w & 0xffu) << 23) * r.inv.x;
     const float sy = __uint_as_float((h0.w & 0xff00u) << 15) * r.inv.y;
@@ -493,30 +474,21 @@ RT_DEV uint32_t visit_qblock(const DScene& S, uint32_t blk, const QRay& r, float
     const float bx = fmaf(__uint_as_float(h0.x), r.inv.x, -r.oi.x);
     const float by = fmaf(__uint_as_float(h0.y), r.inv.y, -r.oi.y);
     const float bz = fmaf(__uint_as_float(h0.z), r.inv.z, -r.oi.z);
-#ifndef RTGO_QF16
     // the plane the ray enters through is the lower one for a positive direction, the upper one for a negative
     const bool nx = (r.sign & 1u) != 0u, ny = (r.sign & 2u) != 0u, nz = (r.sign & 4u) != 0u;
     uint32_t near_[3][2], far_[3][2];
     near_[0][0] = nx ? qb.z : qa.x; near_[0][1] = nx ? qb.w : qa.y; far_[0][0] = nx ? qa.x : qb.z; far_[0][1] = nx ? qa.y : qb.w;
     near_[1][0] = ny ? qc.x : qa.z; near_[1][1] = ny ? qc.y : qa.w; far_[1][0] = ny ? qa.z : qc.x; far_[1][1] = ny ? qa.w : qc.y;
     near_[2][0] = nz ? qc.z : qb.x; near_[2][1] = nz ? qc.w : qb.y; far_[2][0] = nz ? qb.x : qc.z; far_[2][1] = nz ? qb.y : qc.w;
-#endif
     uint32_t hit = 0;
 #pragma unroll
     for (int k = 7; k >= 0; --k) {  // slot 7 first: every slot shifts the mask left and adds its bit
         // a NaN (0 * inf for a direction component of 0) drops out of fmaxf / fminf: that axis then culls nothing
-#ifdef RTGO_QF16
-        const float tn = fmaxf(fmaxf(fmaf(qplane(nX, k), sx, bx), fmaf(qplane(nY, k), sy, by)),
-                               fmaxf(fmaf(qplane(nZ, k), sz, bz), tmin));
-        const float tf = fminf(fminf(fmaf(qplane(fX, k), sx, bx), fmaf(qplane(fY, k), sy, by)),
-                               fminf(fmaf(qplane(fZ, k), sz, bz), tmax));
-#else
         const int w = k >> 2, b = k & 3;
         const float tn = fmaxf(fmaxf(fmaf(qbyte(near_[0][w], b), sx, bx), fmaf(qbyte(near_[1][w], b), sy, by)),
                                fmaxf(fmaf(qbyte(near_[2][w], b), sz, bz), tmin));
         const float tf = fminf(fminf(fmaf(qbyte(far_[0][w], b), sx, bx), fmaf(qbyte(far_[1][w], b), sy, by)),
                                fminf(fmaf(qbyte(far_[2][w], b), sz, bz), tmax));
-#endif
 #ifdef RTGO_HITMASK_CARRY
         // hit = 2 * hit + (tn <= tf): the compare's lane mask goes in as the carry of an add (k_shadow 354 -> 353 ms
         // against compare + select + or)
@@ -628,42 +600,27 @@ RT_DEV bool next_qblock(const TraceStack& st, const uint4& h1, uint32_t present,
 // the exact ones, so a miss here is a miss there)
 RT_DEV uint32_t beam_visit_qblock(const DScene& S, uint32_t blk, const Beam& bm, uint4* h1_out, uint32_t* present_out) {
     const uint4* q = S.qblocks + kQBlockQuads * (size_t)blk;
-#ifdef RTGO_QF16
-    const uint32_t nx = bm.sign & 1u, ny = (bm.sign >> 1) & 1u, nz = bm.sign >> 2;
-    const uint4 h0 = q[0], h1 = q[1];
-    const uint4 nX = q[2 + nx], fX = q[3 - nx], nY = q[4 + ny], fY = q[5 - ny], nZ = q[6 + nz], fZ = q[7 - nz];
-#else
     const uint4 h0 = q[0], h1 = q[1], qa = q[2], qb = q[3], qc = q[4];
-#endif
     const float ex = __uint_as_float((h0.w & 0xffu) << 23), ey = __uint_as_float((h0.w & 0xff00u) << 15), ez = __uint_as_float((h0.w & 0xff0000u) << 7);
     // bound = (origin + q * step) * inv + c, entry and exit with their own inv and c (Beam)
     const float snx = ex * bm.inv_n.x, sny = ey * bm.inv_n.y, snz = ez * bm.inv_n.z;
     const float sfx = ex * bm.inv_f.x, sfy = ey * bm.inv_f.y, sfz = ez * bm.inv_f.z;
     const float bnx = fmaf(__uint_as_float(h0.x), bm.inv_n.x, bm.c_n.x), bny = fmaf(__uint_as_float(h0.y), bm.inv_n.y, bm.c_n.y), bnz = fmaf(__uint_as_float(h0.z), bm.inv_n.z, bm.c_n.z);
     const float bfx = fmaf(__uint_as_float(h0.x), bm.inv_f.x, bm.c_f.x), bfy = fmaf(__uint_as_float(h0.y), bm.inv_f.y, bm.c_f.y), bfz = fmaf(__uint_as_float(h0.z), bm.inv_f.z, bm.c_f.z);
-#ifndef RTGO_QF16
     const bool nx = (bm.sign & 1u) != 0u, ny = (bm.sign & 2u) != 0u, nz = (bm.sign & 4u) != 0u;
     uint32_t near_[3][2], far_[3][2];
     near_[0][0] = nx ? qb.z : qa.x; near_[0][1] = nx ? qb.w : qa.y; far_[0][0] = nx ? qa.x : qb.z; far_[0][1] = nx ? qa.y : qb.w;
     near_[1][0] = ny ? qc.x : qa.z; near_[1][1] = ny ? qc.y : qa.w; far_[1][0] = ny ? qa.z : qc.x; far_[1][1] = ny ? qa.w : qc.y;
     near_[2][0] = nz ? qc.z : qb.x; near_[2][1] = nz ? qc.w : qb.y; far_[2][0] = nz ? qb.x : qc.z; far_[2][1] = nz ? qb.y : qc.w;
-#endif
     uint32_t miss = 0;
 #pragma unroll
     for (int k = 7; k >= 0; --k) {
         // a NaN (0 * inf, inf - inf) drops out of fmaxf / fminf: that bound then culls nothing
-#ifdef RTGO_QF16
-        const float lo = fmaxf(fmaxf(fmaf(qplane(nX, k), snx, bnx), fmaf(qplane(nY, k), sny, bny)),
-                               fmaxf(fmaf(qplane(nZ, k), snz, bnz), bm.s0));
-        const float hi = fminf(fminf(fmaf(qplane(fX, k), sfx, bfx), fmaf(qplane(fY, k), sfy, bfy)),
-                               fminf(fmaf(qplane(fZ, k), sfz, bfz), bm.s1));
-#else
         const int w = k >> 2, b = k & 3;
         const float lo = fmaxf(fmaxf(fmaf(qbyte(near_[0][w], b), snx, bnx), fmaf(qbyte(near_[1][w], b), sny, bny)),
                                fmaxf(fmaf(qbyte(near_[2][w], b), snz, bnz), bm.s0));
         const float hi = fminf(fminf(fmaf(qbyte(far_[0][w], b), sfx, bfx), fmaf(qbyte(far_[1][w], b), sfy, bfy)),
                                fminf(fmaf(qbyte(far_[2][w], b), sfz, bfz), bm.s1));
-#endif
         miss = (miss << 1) | (lo <= hi ? 0u : 1u);
     }
     *h1_out = h1;

@@ -1116,39 +1116,8 @@ struct HostScene {
     std::vector<DMaterial> mats;
     std::vector<DLight> lights;
     int n_pos = 0;
-#ifdef RTGO_QF16
-    std::vector<uint32_t> qblocks16;  // the quantised blocks with float16 planes, 32 words each (device_math.hpp visit_qblock)
-#endif
 };
 
-#ifdef RTGO_QF16
-// 0..255 as float16 bits (exact)
-static inline uint32_t half_bits_of_byte(uint32_t v) {
-    if (v == 0) return 0u;
-    int e = 31 - __builtin_clz(v);
-    return ((uint32_t)(e + 15) << 10) | ((v << (10 - e)) & 0x3ffu);
-}
-// FlatTree::qblocks (octree.hpp QBlock: planes as bytes, 20 words) -> 32 words: words 0..7 unchanged, then per axis the
-// lower and the upper planes of slots 0..7 as float16, two slots per word
-static void expand_qblocks(const std::vector<uint32_t>& q, std::vector<uint32_t>* out) {
-    const size_t n = q.size() / kQBlockWords;
-    out->assign(n * 32, 0u);
-    host_chunks((int64_t)n, [&](int64_t b0, int64_t b1) {
-        for (int64_t b = b0; b < b1; ++b) {
-            const uint32_t* w = q.data() + (size_t)b * kQBlockWords;
-            uint32_t* o = out->data() + (size_t)b * 32;
-            for (int i = 0; i < 8; ++i) o[i] = w[i];
-            const uint8_t* qlo = reinterpret_cast<const uint8_t*>(w + 8);
-            const uint8_t* qhi = reinterpret_cast<const uint8_t*>(w + 14);
-            for (int a = 0; a < 3; ++a)
-                for (int k = 0; k < 8; k += 2) {
-                    o[8 + 8 * a + (k >> 1)] = half_bits_of_byte(qlo[8 * a + k]) | (half_bits_of_byte(qlo[8 * a + k + 1]) << 16);
-                    o[12 + 8 * a + (k >> 1)] = half_bits_of_byte(qhi[8 * a + k]) | (half_bits_of_byte(qhi[8 * a + k + 1]) << 16);
-                }
-        }
-    });
-}
-#endif
 
 static int build_host_scene(const rt_scene_desc* desc, HostScene* h, Laps& lap) {
     {
@@ -1233,9 +1202,6 @@ static int build_host_scene(const rt_scene_desc* desc, HostScene* h, Laps& lap) 
         if (l.kind != RT_LIGHT_AMBIENT) ++n_pos;
     }
     h->n_pos = n_pos;
-#ifdef RTGO_QF16
-    expand_qblocks(h->flat.qblocks, &h->qblocks16);
-#endif
     lap("tables");
     return RT_OK;
 }
@@ -1312,13 +1278,8 @@ static int finish_scene(const rt_scene_desc* desc, const HostScene& h, rt_scene*
     HIP_TRY_S(hipMalloc(&s->d_recs, rec_bytes));
     HIP_TRY_S(hipMemset(s->d_recs, 0, rec_bytes));  // the padding record is fetched (and masked out) for trailing absent slots
     if (!h.flat.records.empty()) HIP_TRY_S(hipMemcpy(s->d_recs, h.flat.records.data(), h.flat.records.size() * sizeof(ChildRecord), hipMemcpyHostToDevice));
-#ifdef RTGO_QF16
-    HIP_TRY_S(hipMalloc(&s->d_qblocks, h.qblocks16.size() * sizeof(uint32_t)));
-    HIP_TRY_S(hipMemcpy(s->d_qblocks, h.qblocks16.data(), h.qblocks16.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-#else
     HIP_TRY_S(hipMalloc(&s->d_qblocks, h.flat.qblocks.size() * sizeof(uint32_t)));
     HIP_TRY_S(hipMemcpy(s->d_qblocks, h.flat.qblocks.data(), h.flat.qblocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-#endif
     HIP_TRY_S(hipMalloc(&s->d_prims, h.prim_words * sizeof(float)));
     HIP_TRY_S(hipMemcpy(s->d_prims, h.prims.get(), h.prim_words * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_tprims, h.prim_words * sizeof(float)));

@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256, 6) void k(const uint32_t* in, float* out) {
     uint32_t w = in[threadIdx.x];
     const h2 h = __builtin_bit_cast(h2, in[threadIdx.x + 256]);
     const float c = 1e-9f;
+    const uint32_t hsub = (in[threadIdx.x + 256] & 0x00ff00ffu) | 0x00010001u;  // two float16 subnormals
     const unsigned long long mask = __ballot(w & 1u);
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 d[8], d2 = {1.0000001f, 0.9999999f};
@@ -69,6 +70,8 @@ __global__ __launch_bounds__(256, 6) void k(const uint32_t* in, float* out) {
             if (OP == 39) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(w));
             if (OP == 40) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
             if (OP == 41) asm volatile("v_mul_f32 %0, 0x3f800001, %0" : "+v"(a[i]));
+            if (OP == 42) asm volatile("v_fma_mix_f32 %0, %1, %0, %2 op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(hsub), "v"(c));  // float16 SUBNORMAL operand
+            if (OP == 43) asm volatile("v_fma_mix_f32 %0, %1, %0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(h), "v"(c));  // upper half
         }
     }
     float s = (float)w;
@@ -136,5 +139,7 @@ int main() {
     run<39>("v_mul_hi_u32", in, out, cus, clk);
     run<40>("v_mov_dpp", in, out, cus, clk);
     run<41>("v_mul_f32_imm", in, out, cus, clk);
+    run<42>("v_fma_mix(subnorm)", in, out, cus, clk);
+    run<43>("v_fma_mix(hi half)", in, out, cus, clk);
     return 0;
 }
