@@ -57,10 +57,11 @@ class TorchDriver:
 
     name = "torchrun"
 
-    def __init__(self, args, spec, scene, mode, mods):
+    def __init__(self, args, mode, mods):
+        """the runtime: torch, this rank's device, the process group (not part of a GenerateImage call)"""
         import torch
 
-        self.torch = torch
+        self.torch, self.mods, self.mode = torch, mods, mode
         abi, backend, rtdist = mods["abi"], mods["backend"], mods["dist"]
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
@@ -83,8 +84,15 @@ class TorchDriver:
             rtdist.init_process_group(self.rank, self.world, rtdist.pick_backend(self.world, n_dev), dev)
         if self.world == 1:
             self.name = "single"
+        self.dev, self.local_rank = dev, local_rank
+        torch.zeros(1, device=dev)  # the runtime's own first-use costs stay out of the frame's clock
+        torch.cuda.synchronize()
+        self.rccl_ranks = self.world if (self.world > 1 and not self.rehearsal) else 0
+
+    def create(self, spec, scene):
+        torch, backend, rtdist, dev = self.torch, self.mods["backend"], self.mods["dist"], self.dev
         t0 = time.perf_counter()
-        self.dscene = backend.DeviceScene(scene, device=local_rank)  # = NewBoundingVolumeHierarchy + upload (raytracer.go:69)
+        self.dscene = backend.DeviceScene(scene, device=self.local_rank)  # = NewBoundingVolumeHierarchy + upload (raytracer.go:69)
         self.create_s = time.perf_counter() - t0
         self.info = self.dscene.info()
         W, H = spec.Width, spec.Height
@@ -93,10 +101,9 @@ class TorchDriver:
         self.stream = torch.cuda.current_stream(dev).cuda_stream
         self.spec = spec
         self.lib_build_s = 0.0
-        self.loop = rtdist.FrameLoop(spec, mode, self.rank, self.world, self.accum, self._share,
+        self.loop = rtdist.FrameLoop(spec, self.mode, self.rank, self.world, self.accum, self._share,
                                      resolve=lambda a: backend.resolve_device(a.data_ptr(), W, H, spec.AntiAliasingFactor,
                                                                               self.rgba.data_ptr(), stream=self.stream))
-        self.rccl_ranks = self.world if (self.world > 1 and not self.rehearsal) else 0
 
     def _share(self, part):
         st = self.dscene.render_accum_device(self.spec, self.accum.data_ptr(), stream=self.stream, part=part)
@@ -129,10 +136,10 @@ class MultiDriver:
 
     name = "rt_multi"
 
-    def __init__(self, args, spec, scene, mode, mods):
-        import numpy as np
-
+    def __init__(self, args, mode, mods):
+        """the runtime: which devices (rt_init also starts each device's HIP warm-up, as a cgo caller's init would)"""
         backend = mods["backend"]
+        self.mods, self.mode, self.args = mods, mode, args
         self.world, self.rank, self.rehearsal = args.gpus, 0, False
         # visible GPUs, counted through the library itself (rt_init also starts each device's runtime warm-up); torch
         # stays out of this process
@@ -149,16 +156,22 @@ class MultiDriver:
                 raise SystemExit(f"--gpus {args.gpus} but only {n_dev} GPU(s) are visible: a measured line needs one GPU per share "
                                  "(--allow-shared-devices rehearses the code path on shared devices and marks the line)")
             self.rehearsal = True
-        devices = [r % n_dev for r in range(args.gpus)]
+        self.devices = [r % n_dev for r in range(args.gpus)]
+        self.rccl_ranks = 0
+
+    def create(self, spec, scene):
+        import numpy as np
+
+        backend, args = self.mods["backend"], self.args
         t0 = time.perf_counter()
-        self.m = backend.MultiDeviceScene(scene, devices)
+        self.m = backend.MultiDeviceScene(scene, self.devices)
         self.create_s = time.perf_counter() - t0
         mi = self.m.info()
         self.rccl_ranks = mi["rccl_ranks"]
         if args.gpus > 1 and not self.rehearsal and self.rccl_ranks != args.gpus:
             raise SystemExit(f"rt_multi made {self.rccl_ranks} RCCL ranks for {args.gpus} GPUs")
         self.info = None
-        self.spec, self.mode = spec, mode
+        self.spec = spec
         self.out = np.zeros((spec.Height, spec.Width, 4), dtype=np.uint8)
         self.lib_build_s = 0.0
 
@@ -211,6 +224,7 @@ def main():
     mode_name = args.mode or ("tiles" if args.config == 5 else "samples")
     mode = abi.RT_PART_TILES if mode_name == "tiles" else abi.RT_PART_SAMPLES
 
+    drv = (MultiDriver if launcher == "rt_multi" else TorchDriver)(args, mode, mods)
     t_scene = time.perf_counter()
     if args.config == 5:
         W, H = args.width or 3840, args.height or 2160
@@ -219,7 +233,7 @@ def main():
         W, H = args.width or 1920, args.height or 1080
         spec, scene = scenes.config3(W, H, args.spp, 16)
     t_described = time.perf_counter()
-    drv = (MultiDriver if launcher == "rt_multi" else TorchDriver)(args, spec, scene, mode, mods)
+    drv.create(spec, scene)
     world, rank = drv.world, drv.rank
 
     # the first frame, cold: with the tree build and the upload before it, this is one GenerateImage call

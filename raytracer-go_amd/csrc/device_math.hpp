@@ -646,10 +646,10 @@ RT_DEV bool beam_meets_record(const DScene& S, uint32_t rec, const Beam& bm) {
 // met is either visited already or still on its stack.  The rays therefore need not start at the root: they resume at
 // the block where the beam stopped, with the beam's stack (config 3, CPU simulation: 8.1 entries; 10.7 instead of 13.2
 // block visits per ray, the visits of inherited blocks that a ray then misses included; 7.7 with those filtered out).
-//   resume[0] = entries of the stack (kResumeRoot: start at the root instead), resume[1] = the block to enter,
-//   resume[2 ..] = the stack, bottom first; all as indices of quantised blocks.
-constexpr int kResumeWords = 16;
-constexpr int kResumeStack = kLdsStackDepth < kResumeWords - 2 ? kLdsStackDepth : kResumeWords - 2;  // entries handed over at most
+//   resume[0] = the block to enter << 8 | entries of the stack (kResumeRoot: start at the root instead),
+//   resume[1 ..] = the stack, bottom first; all as indices of quantised blocks (below 2^24).  48 bytes per pair.
+constexpr int kResumeWords = 12;
+constexpr int kResumeStack = kLdsStackDepth < kResumeWords - 1 ? kLdsStackDepth : kResumeWords - 1;  // entries handed over at most
 constexpr uint32_t kResumeRoot = 0xffffffffu;
 RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, const Beam& bm, uint32_t* cur_out, int* sp_out) {
     uint32_t cur = 0u;  // block index; the root is block 0
@@ -681,9 +681,8 @@ RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, cons
 // The state of a stopped beam walk, as the pair's rays will read it
 RT_DEV void write_resume(const TraceStack& st, uint32_t cur, int sp, uint32_t* resume) {
     if (sp <= kResumeStack) {
-        resume[0] = (uint32_t)sp;
-        resume[1] = cur;
-        for (int k = 0; k < sp; ++k) resume[2 + k] = st.get(k);
+        resume[0] = (cur << 8) | (uint32_t)sp;
+        for (int k = 0; k < sp; ++k) resume[1 + k] = st.get(k);
     } else {
         resume[0] = kResumeRoot;
     }
@@ -735,19 +734,19 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
     if (live && resume) {  // the state a beam walk left for this ray's pair (beam_is_clear): at most kResumeStack entries,
         // all fetched at once and stored to the LDS part of the stack without a branch per entry
         const uint4* q = reinterpret_cast<const uint4*>(resume);
-        const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3];
-        const uint32_t e[kResumeWords] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+        const uint4 w0 = q[0], w1 = q[1], w2 = q[2];
+        const uint32_t e[kResumeWords] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
         if (e[0] != kResumeRoot) {
-            cur = e[1];
+            cur = e[0] >> 8;
             // Of the blocks on the beam's stack this ray keeps those whose box it meets (config 3, CPU simulation: it
             // misses 2.9 of the 8.1, each a block visit that would find nothing).  No branch per entry: every entry is
             // stored at the top, which only moves for the ones that are kept; entries past e[0] test block 0 and are dropped.
-            const uint32_t n = e[0];
+            const uint32_t n = e[0] & 0xffu;
 #pragma unroll
             for (int k = 0; k < kResumeStack; ++k) {
                 const bool in_use = (uint32_t)k < n;
                 if (__ballot(in_use) == 0ull) break;  // wave-uniform
-                const uint32_t b = in_use ? e[2 + k] : 0u;
+                const uint32_t b = in_use ? e[1 + k] : 0u;
                 const float4 lo4 = S.block_box[2 * (size_t)b], hi4 = S.block_box[2 * (size_t)b + 1];
                 const float x0 = fmaf(lo4.x, r.inv.x, -r.oi.x), x1 = fmaf(hi4.x, r.inv.x, -r.oi.x);
                 const float y0 = fmaf(lo4.y, r.inv.y, -r.oi.y), y1 = fmaf(hi4.y, r.inv.y, -r.oi.y);

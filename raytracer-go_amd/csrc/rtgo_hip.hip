@@ -794,6 +794,7 @@ struct Lane {
     size_t h_counter_words = 0;
     hipEvent_t ev_snap[2] = {}, ev_frame[2] = {};
     bool ev_ok = false;
+    DevBuf beam_state;  // per (path, light) of a batch: what a pair's rays resume from (48 bytes); only calls that walk pair beams make it
     std::vector<hipEvent_t> ev_pool;  // per-stage timing of a call that asks for stats: 4 per (batch, bounce), reused
     hipStream_t stream = nullptr;     // lanes beyond the first: their own stream (lane 0 runs on the caller's)
     hipEvent_t ev_join = nullptr;
@@ -838,8 +839,7 @@ constexpr size_t kAlign = 256;
 inline size_t align_up(size_t n) { return (n + kAlign - 1) / kAlign * kAlign; }
 
 // Lays the arrays of a batch workspace out over `base` (nullptr: only measure).  Returns the bytes needed.
-size_t carve_work(Work* w, unsigned char* base, int64_t paths, int depth, int lpos, unsigned long long overflow_entries,
-                  unsigned long long resume_pairs = 0) {
+size_t carve_work(Work* w, unsigned char* base, int64_t paths, int depth, int lpos, unsigned long long overflow_entries) {
     size_t off = 0;
     auto take = [&](size_t n) { unsigned char* p = base ? base + off : nullptr; off += align_up(n); return p; };
     const size_t P = (size_t)paths, L = (size_t)(lpos > 0 ? lpos : 1);
@@ -858,7 +858,7 @@ size_t carve_work(Work* w, unsigned char* base, int64_t paths, int depth, int lp
     w->counters = (uint32_t*)take((size_t)(3 * depth + 8) * sizeof(uint32_t));
     w->frame_counters = (unsigned long long*)take(4 * sizeof(unsigned long long));
     w->overflow = (uint32_t*)take((size_t)overflow_entries * sizeof(uint32_t));
-    w->beam_state = resume_pairs ? (uint32_t*)take((size_t)resume_pairs * kResumeWords * sizeof(uint32_t)) : nullptr;
+    w->beam_state = nullptr;  // a buffer of its own (Lane::beam_state), made by the calls that walk pair beams
     return off;
 }
 
@@ -883,13 +883,11 @@ int ensure_work(rt_scene* s, Lane& ln, int64_t paths, int depth, int lpos, unsig
     const int nd = std::max(depth, a.depth), nl = std::max(lpos, a.lpos);
     const unsigned long long ne = std::max(entries, a.overflow_entries);
     Work w{};
-    unsigned long long n_resume = (unsigned long long)np * (unsigned long long)std::max(1, nl);  // one state per (path, light)
-    if (n_resume * kResumeWords * sizeof(uint32_t) > ((size_t)4 << 30)) n_resume = 0;  // many lights: the rays then start at the root
-    const size_t need = carve_work(&w, nullptr, np, nd, nl, ne, n_resume);
+    const size_t need = carve_work(&w, nullptr, np, nd, nl, ne);
     if (a.base) { (void)hipFree(a.base); a.base = nullptr; a.bytes = 0; a.paths = 0; a.depth = 0; a.lpos = 0; a.overflow_entries = 0; }
     HIP_TRY(hipMalloc((void**)&a.base, need));
     a.bytes = need;
-    (void)carve_work(&a.wk, a.base, np, nd, nl, ne, n_resume);
+    (void)carve_work(&a.wk, a.base, np, nd, nl, ne);
     a.paths = np; a.depth = nd; a.lpos = nl; a.overflow_entries = ne;
     a.wk.overflow_stride = s->spill > 0 ? (uint32_t)(ne / (unsigned long long)(s->spill + 1)) : 0u;
     const size_t words = (size_t)(3 * nd + 8);
@@ -1353,6 +1351,7 @@ void rt_scene_destroy(rt_scene* s) {
     (void)hipDeviceSynchronize();  // a call without stats may have left its tail on a stream
     for (Lane& ln : s->lanes) {
         if (ln.arena.owned && ln.arena.base) (void)hipFree(ln.arena.base);
+        ln.beam_state.release();
         if (ln.h_counters) (void)hipHostFree(ln.h_counters);
         if (ln.ev_ok) {
             for (auto& e : ln.ev_snap) if (e) (void)hipEventDestroy(e);
@@ -1483,6 +1482,16 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
     const bool beams = beam_env ? beam_env[0] != '0' : (s->info.n_shapes >= 256 && reps >= 4);
     const char* resume_env = std::getenv("RTGO_RESUME");  // "0": rays start at the root, not where their pair's beam stopped (A/B switch)
     const bool resume_on = !(resume_env && resume_env[0] == '0');
+    // what a pair's rays resume from: 48 bytes per (path, light) of a batch, in a buffer of the lane's own that only
+    // calls which walk pair beams make (and only entry points that may allocate; without it the rays start at the root)
+    wk.beam_state = nullptr;
+    if (beams && resume_on && may_create_events && L > 0 && reps > 0) {
+        const unsigned long long need = (unsigned long long)P.batch_paths * (unsigned long long)L * kResumeWords * sizeof(uint32_t);
+        if (need <= (4ull << 30)) {  // (many lights: the rays then start at the root)
+            HIP_TRY(ln.beam_state.ensure((size_t)need));
+            wk.beam_state = (uint32_t*)ln.beam_state.p;
+        }
+    }
     const bool staged = timed && may_create_events;  // per-stage events (and their host-side list) only where the entry point may allocate
     size_t ev_used = 0;
     auto stamp = [&]() -> int {  // one timing event on the stream, from the pool (grown only where the entry point may allocate)

@@ -1,7 +1,9 @@
-"""profiles/r02/bounds.json from one run of scripts/profile_r02.sh: per-frame counter totals of k_shadow (PMC passes over
+"""profiles/r03/bounds.json from one run of scripts/profile_r03.sh: per-frame counter totals of k_shadow (PMC passes over
 bench.py --steps 1 --warmup 0, which renders the cold frame and one timed frame) + the unit rates calibrated on the
 same box (scripts/calib.hip).  bench.py prices the kernel's live time against them.
-    python scripts/make_bounds.py gpurun_out/prof_<tag> profiles/r02 <tag>"""
+The file names the build the counts were taken on (rt_build_info of the library the profiled run loaded, from the
+run's own JSON line): bench.py prints "stale" instead of a fraction when the loaded library is another.
+    python scripts/make_bounds.py gpurun_out/prof_<tag> profiles/r03 <tag>"""
 import ast
 import json
 import os
@@ -15,12 +17,17 @@ os.makedirs(dst, exist_ok=True)
 
 def kernel_counters(path, kernel="k_shadow"):
     for line in open(path):
-        m = re.match(rf"^{kernel} calls (\d+) (\{{.*\}})\s*$", line)
+        m = re.match(rf"^{kernel}(?:<\w+>)? calls (\d+) (\{{.*\}})\s*$", line)
         if m:
             return int(m.group(1)), {k: float(v) for k, v in ast.literal_eval(m.group(2)).items()}
     raise SystemExit(f"no {kernel} line in {path}")
 
 
+bench_line = json.loads(open(os.path.join(src, "bench_trace.log")).read().strip().splitlines()[-1])
+build = bench_line["build"]
+for name in ("bench_pmc_units.log", "bench_pmc_fetch.log", "bench_pmc_l2.log", "bench_pmc_mix.log"):
+    other = json.loads(open(os.path.join(src, name)).read().strip().splitlines()[-1])["build"]
+    assert other == build, (name, other, build)
 calls, u = kernel_counters(os.path.join(src, "pmc_units.txt"))
 _, f = kernel_counters(os.path.join(src, "pmc_fetch.txt"))
 _, l2 = kernel_counters(os.path.join(src, "pmc_l2.txt"))
@@ -41,6 +48,7 @@ l2_srv = 1024.0 / calib["gather_share1"]["lane_bytes_per_cycle_per_cu"]     # ..
 out = {
     "workload": {"width": 1920, "height": 1080, "spp": 64, "config": "config3"},
     "kernel": "k_shadow", "launches_per_frame": launches, "frames_profiled": frames, "tag": tag,
+    "build": build,
     "per_frame": {
         "valu_insts": u["SQ_INSTS_VALU"] / frames,
         "salu_insts": u["SQ_INSTS_SALU"] / frames,
@@ -91,6 +99,8 @@ out = {
     },
 }
 json.dump(out, open(os.path.join(dst, "bounds.json"), "w"), indent=1)
-for name in ("kernel_stats.csv", "pmc_units.txt", "pmc_fetch.txt", "pmc_l2.txt", "pmc_mix.txt", "calib.json", "calib_mix.txt"):
+for name in ("kernel_stats.csv", "pmc_units.txt", "pmc_fetch.txt", "pmc_l2.txt", "pmc_mix.txt", "pmc_wr.txt", "calib.json", "calib_mix.txt"):
+    if not os.path.exists(os.path.join(src, name)):
+        continue
     shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
 print(json.dumps(out["per_frame"], indent=1))
