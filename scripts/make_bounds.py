@@ -23,10 +23,13 @@ def kernel_counters(path, kernel="k_shadow"):
     raise SystemExit(f"no {kernel} line in {path}")
 
 
-bench_line = json.loads(open(os.path.join(src, "bench_trace.log")).read().strip().splitlines()[-1])
-build = bench_line["build"]
+def bench_line(name):  # bench.py's JSON line among rocprofv3's own messages
+    return json.loads(next(l for l in open(os.path.join(src, name)) if l.startswith('{"metric"')))
+
+
+build = bench_line("bench_trace.log")["build"]
 for name in ("bench_pmc_units.log", "bench_pmc_fetch.log", "bench_pmc_l2.log", "bench_pmc_mix.log"):
-    other = json.loads(open(os.path.join(src, name)).read().strip().splitlines()[-1])["build"]
+    other = bench_line(name)["build"]
     assert other == build, (name, other, build)
 calls, u = kernel_counters(os.path.join(src, "pmc_units.txt"))
 _, f = kernel_counters(os.path.join(src, "pmc_fetch.txt"))
