@@ -188,6 +188,7 @@ RT_DEV bool prim_occludes(const DScene& S, uint32_t prim, f3 o, f3 d, float tmin
 #ifdef RTGO_PROF
 __device__ unsigned long long g_prof[8];
 __device__ unsigned long long g_prof3[65 + 64];  // shadow-ray walk: [w] iterations with w walking lanes, [65 + i] wave rounds of i iterations (63: or more)
+__device__ unsigned long long g_prof5[4];  // pairs of consecutive shadow-ray rounds of a wavefront: [0] pairs, [1] sum of (iterations a + iterations b), [2] sum of max over lanes of (visits a + visits b), [3] sum of max(iters a, iters b, ceil(visits of both / 64))
 __device__ unsigned long long g_prof4[64];  // walking lanes summed per iteration index (63: and later)
 __device__ unsigned long long g_prof2[4];  // shadow-ray walk: iterations, lanes only holding leaves, idle lanes, shape loops  // [2i] = times a wavefront passed point i, [2i+1] = lanes active there
 #define RT_PROF_POINT(i)                                                          \
@@ -722,7 +723,11 @@ RT_DEV uint32_t wave_scan_max(uint32_t x) {
 // SAME_TMIN: tmin is the same for every lane of the wavefront (k_shadow's constant), so a lane that tests
 // another lane's shape need not fetch it with the rest of that lane's ray.
 template <bool SAME_TMIN>
-RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 d, float tmin, float tmax, const uint32_t* resume = nullptr) {
+RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 d, float tmin, float tmax, const uint32_t* resume = nullptr
+#ifdef RTGO_PROF
+                     , uint32_t* prof_visits = nullptr, uint32_t* prof_iters_out = nullptr
+#endif
+                     ) {
     // Called by ALL 64 lanes of a wavefront (live = this lane has a ray).  The lanes walk their own rays, but
     // the shape loop is shared: the queued shapes of all lanes are dealt out evenly, one shape per lane and
     // round, whoever's ray it belongs to.  (Lane utilisation of the shape tests 0.91, against 0.38 when every
@@ -819,6 +824,7 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
 
 #ifdef RTGO_PROF
     int prof_iters = 0;
+    uint32_t prof_my_visits = 0;
 #endif
     for (;;) {
         uint4 h1 = make_uint4(0u, 0u, 0u, 0u);
@@ -838,6 +844,9 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
         }
 #endif
         if (walking) {  // a box that ends before tmin holds no accepted hit
+#ifdef RTGO_PROF
+            ++prof_my_visits;
+#endif
             const uint32_t hit = visit_qblock(S, cur, r, tmin, tmax, &h1, &present);
             leaf_mask = hit & (h1.x >> 24);
             inner_mask = hit & ~(h1.x >> 24);
@@ -855,6 +864,8 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
     }
 #ifdef RTGO_PROF
     if (lane == 0) atomicAdd(&g_prof3[65 + (prof_iters < 63 ? prof_iters : 63)], 1ull);
+    if (prof_visits) *prof_visits = prof_my_visits;
+    if (prof_iters_out) *prof_iters_out = (uint32_t)prof_iters;
 #endif
     return occ;
 }

@@ -480,6 +480,9 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
     const int lane = (int)__lane_id();
     unsigned long long launched = 0;  // wave-uniform
     const int iters = MANY_REPS ? (B.reps + group - 1) >> group_shift : 1;  // > 1 only when reps > 64
+#ifdef RTGO_PROF
+    uint32_t prof_prev_visits = 0, prof_prev_iters = 0;
+#endif
     for (uint32_t it = 0; it < rounds; ++it) {
         // interleaved, not a contiguous range per block: ranges differ too much in cost (1024 blocks: 1760 vs 708 ms)
         const uint32_t pi = it * pairs_per_round + my_pair;  // (plan_render keeps n_pairs + a round of pairs below 2^32)
@@ -523,7 +526,25 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
             launched += (unsigned long long)__popcll(__ballot(traced));
             RT_PROF_POINT(2);  // shadow-ray rounds
             // all 64 lanes call: lanes without a ray of their own test shapes for the others
+#ifdef RTGO_PROF
+            // what fusing two consecutive rounds of a wavefront (a lane going on to its second ray as soon as its first is done) could give
+            uint32_t pv = 0, pit = 0;
+            const bool occ = occluded<true>(S, st, traced, p, dir, 0.01f, dist, beam_state ? beam_state + (size_t)pi * kResumeWords : nullptr, &pv, &pit);
+            if (it & 1u) {
+                uint32_t both = pv + prof_prev_visits, sum = both, mx = both;
+                for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off); const uint32_t o2 = __shfl_xor(mx, off); mx = mx > o2 ? mx : o2; }
+                if (lane == 0) {
+                    const uint32_t lower = (sum + 63u) / 64u, m2 = pit > prof_prev_iters ? pit : prof_prev_iters;
+                    atomicAdd(&g_prof5[0], 1ull);
+                    atomicAdd(&g_prof5[1], (unsigned long long)(pit + prof_prev_iters));
+                    atomicAdd(&g_prof5[2], (unsigned long long)mx);
+                    atomicAdd(&g_prof5[3], (unsigned long long)(lower > m2 ? lower : m2));
+                }
+            }
+            prof_prev_visits = pv; prof_prev_iters = pit;
+#else
             const bool occ = occluded<true>(S, st, traced, p, dir, 0.01f, dist, beam_state ? beam_state + (size_t)pi * kResumeWords : nullptr);
+#endif
             // the visible repetitions of a (hit, light) counted over its lane group: an integer, no summation order
             const unsigned long long m = __ballot(traced && !occ);
             count += (uint32_t)__popcll((m >> (lane & ~(group - 1))) & low_mask);
@@ -1968,6 +1989,7 @@ static int rt_multi_render_impl(rt_multi* m, const rt_image_spec* spec, int32_t 
         ncclResult_t e = m->rccl.GroupStart();
         for (int r = 0; r < n && e == ncclSuccess; ++r) {
             rt_scene* s = m->scenes[(size_t)r];
+            if (hipSetDevice(s->device) != hipSuccess) { e = ncclUnhandledCudaError; break; }  // the rank's stream is this device's
             e = m->rccl.Reduce(s->accum.p, s->accum.p, count, ncclFloat, ncclSum, 0, m->comms[(size_t)r], m->streams[(size_t)r]);
         }
         const ncclResult_t e2 = m->rccl.GroupEnd();
@@ -2038,6 +2060,7 @@ int rt_debug_prof(unsigned long long* out8, int reset) {
     HIP_TRY(hipMemcpyFromSymbol(out8 + 8, HIP_SYMBOL(rtgo::g_prof2), 4 * sizeof(unsigned long long)));  // out8 holds 12 + 129 + 64
     HIP_TRY(hipMemcpyFromSymbol(out8 + 12, HIP_SYMBOL(rtgo::g_prof3), (65 + 64) * sizeof(unsigned long long)));
     HIP_TRY(hipMemcpyFromSymbol(out8 + 12 + 129, HIP_SYMBOL(rtgo::g_prof4), 64 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyFromSymbol(out8 + 12 + 129 + 64, HIP_SYMBOL(rtgo::g_prof5), 4 * sizeof(unsigned long long)));
     if (reset) {
         const unsigned long long z[8] = {};
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtgo::g_prof), z, sizeof(z)));

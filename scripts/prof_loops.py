@@ -9,7 +9,7 @@ scenes = importlib.import_module("raytracer-go_amd.scenes")
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1080
 spec, scene = scenes.config3(1920, rows, 64 if rows < 1080 else 16, 16, asset_dir=os.path.join(ROOT, "tests/golden"))
 dev = backend.DeviceScene(scene)
-out = (ctypes.c_ulonglong * (12 + 129 + 64))()
+out = (ctypes.c_ulonglong * (12 + 129 + 64 + 4))()
 L = backend.lib()
 acc, st = dev.render_accum(spec)
 L.rt_debug_prof(out, 0)
@@ -42,3 +42,7 @@ if tot:
     for i in range(0, 63, 3):
         if reach[i]:
             print("  it %2d: %.3f of iterations, %.1f lanes walking" % (i, reach[i] / total_it, sw[i] / reach[i]))
+f = v[12 + 129 + 64:12 + 129 + 68]
+if f[0]:
+    print("two consecutive rounds of a wavefront fused (a lane starts its second ray when its first is done): %.1f iterations now, "
+          "%.1f fused (max over lanes of the two rays' visits), %.1f at best (perfect balance)" % (f[1] / f[0], f[2] / f[0], f[3] / f[0]))
