@@ -2050,7 +2050,7 @@ int rt_multi_get_info(const rt_multi* m, rt_multi_info* out) {
 const char* rt_build_info(void) {
     return "src=" RTGO_SRC_HASH " shadow_waves=" RTGO_STR(RTGO_SHADOW_WAVES) " beam_waves=" RTGO_STR(RTGO_BEAM_WAVES)
            " extend_waves=" RTGO_STR(RTGO_EXTEND_WAVES) " lds_stack=" RTGO_STR(RTGO_LDS_STACK) " pend_cap=" RTGO_STR(RTGO_PEND_CAP)
-           " flush_lanes=" RTGO_STR(RTGO_FLUSH_LANES) " visit_batch=" RTGO_STR(RTGO_VISIT_BATCH) " max_grid=" RTGO_STR(RTGO_MAX_GRID);
+           " flush_lanes=" RTGO_STR(RTGO_FLUSH_LANES) " steal=" RTGO_STR(RTGO_STEAL) " visit_batch=" RTGO_STR(RTGO_VISIT_BATCH) " max_grid=" RTGO_STR(RTGO_MAX_GRID);
 }
 
 #ifdef RTGO_PROF
