@@ -168,3 +168,27 @@ def test_rmse_against_converged_reference_full_meshes(backend, scenes, gold_dir,
     print(name, "rmse", rmse, "ratio", rmse[256] / rmse[16], "mean bias", bias)
     assert rmse[256] < 0.45 * rmse[16]
     assert bias < 2e-3
+
+
+def test_headline_frame_size_against_float64_reference(backend, bridge, scenes, gold_dir):
+    """the float64 reference-faithful checks ran at 128x72; at the headline's frame size the only
+    check was the device against itself.  Here: config 3 at 1920x1080, 1 spp, the middle 540 rows — 1.04 M paths, their
+    50 M reference-equivalent shadow rays — device against the oracle's F64_DIJKSTRA mode (the reference's insertion
+    octree walked best-first in float64, every shadow ray traced): fraction of pixels whose colour agrees within
+    1/255, PhongBlinn hits and reference-equivalent rays of those rows."""
+    spec, scene = scenes.config3(1920, 1080, 1, 16, asset_dir=gold_dir)
+    r0, r1 = 270, 810
+    with backend.DeviceScene(scene) as dev, bridge.OracleScene(scene) as osc:
+        acc, st = dev.render_accum(spec)
+        ref, _, ctr = osc.render(spec, mode=bridge.F64_DIJKSTRA, rows=(r0, r1), rgba=False)
+        # the same rows through the float32 mirror: ray for ray what the device does
+        ref32, _, ctr32 = osc.render(spec, mode=bridge.F32_STACK, rows=(r0, r1), rgba=False)
+    d = np.abs(acc[r0:r1].astype(np.float64) - ref[r0:r1]).max(-1)
+    within = (d <= 1 / 255).mean()
+    d32 = np.abs(acc[r0:r1].astype(np.float64) - ref32[r0:r1]).max(-1)
+    print(f"1920x1080 rows {r0}..{r1}: {100 * within:.3f} % of {d.size} pixels within 1/255 of the float64 frame (max {d.max():.3f}); "
+          f"against the float32 mirror: {100 * (d32 <= 1e-3).mean():.4f} % within 1e-3 (max {d32.max():.2e}); "
+          f"float64 phong hits {ctr['phong_hits']}, shadow rays {ctr['rays_shadow']}")
+    assert ctr["rays_primary"] == (r1 - r0) * spec.Width
+    assert within >= 0.985
+    assert (d32 <= 1e-3).mean() >= 0.999
