@@ -273,7 +273,10 @@ int rt_generate_image_multi(const rt_scene_desc* desc, const rt_image_spec* spec
  * (accelerationstructures.go:81-124).  rays: n * 8 floats {ox,oy,oz, dx,dy,dz, tMin, 0};
  * prim_out[n]: shape index or -1; t_out[n]: hit t (undefined on miss).
  * any_hit != 0 runs the shadow-ray traversal instead (light.go:141-160 semantics with
- * ray slot 7 = tMax): prim_out = 1 if occluded else 0. */
+ * ray slot 7 = tMax): prim_out = 1 if occluded else 0.  any_hit == 2: the same with ONE tMin for
+ * the whole call (ray 0's slot 6; light.go:150 uses 0.01 for every shadow ray): the form of the
+ * walk the render path itself runs, in which idle lanes of a wavefront walk subtrees for the
+ * lanes that are still busy. */
 int rt_trace_rays(rt_scene* scene, const float* rays, int64_t n, int32_t any_hit,
                   int32_t* prim_out, float* t_out);
 

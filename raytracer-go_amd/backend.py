@@ -156,13 +156,14 @@ class DeviceScene:
                                                    C.c_void_p(stream or 0), C.addressof(st) if want_stats else None))
         return st
 
-    def trace_rays(self, rays, any_hit=False):
-        """rays (n, 8) float32 {o, d, tMin, tMax} -> (shape index or -1 [any_hit: 0/1], t)."""
+    def trace_rays(self, rays, any_hit=False, uniform_tmin=False):
+        """rays (n, 8) float32 {o, d, tMin, tMax} -> (shape index or -1 [any_hit: 0/1], t).
+        uniform_tmin (with any_hit): every ray uses ray 0's tMin — the walk as the render path runs it."""
         rays = np.ascontiguousarray(rays, dtype=np.float32)
         n = rays.shape[0]
         prim = np.empty(n, dtype=np.int32)
         t = np.empty(n, dtype=np.float32)
-        _check(lib().rt_trace_rays(self._h, rays.ctypes.data, n, 1 if any_hit else 0, prim.ctypes.data, t.ctypes.data))
+        _check(lib().rt_trace_rays(self._h, rays.ctypes.data, n, (2 if uniform_tmin else 1) if any_hit else 0, prim.ctypes.data, t.ctypes.data))
         return prim, t
 
     def scatter_probe(self, spec, rays6, keys, seed=0x5EED):

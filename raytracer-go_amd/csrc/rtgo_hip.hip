@@ -638,7 +638,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_probe(DScene S, Work Wk, const
         const uint32_t i = base + threadIdx.x;
         const bool live = i < n;
         const float* q = rays + (size_t)(live ? i : 0u) * 8;
-        if (any_hit) {
+        if (any_hit == 2) {
+            // the instantiation k_shadow uses — one tMin for the whole call (ray 0's), idle lanes taking over
+            // subtrees of walking lanes — on the caller's own rays
+            const bool occ = occluded<true>(S, st, live, mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), rays[6], q[7]);
+            if (live) { prim_out[i] = occ ? 1 : 0; t_out[i] = 0.0f; }
+        } else if (any_hit) {
             const bool occ = occluded<false>(S, st, live, mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), q[6], q[7]);
             if (live) { prim_out[i] = occ ? 1 : 0; t_out[i] = 0.0f; }
         } else if (live) {

@@ -88,9 +88,20 @@ def test_full_size_any_hit_agrees_with_closest_hit(backend, scenes, gold_dir):
         probe[:, 7] = th * (1 + 1e-3)  # the nearest hit lies inside the interval
         occ, _ = dev.trace_rays(probe, any_hit=True)
         assert (occ == 0).mean() <= 1e-5
+        # the walk as k_shadow runs it (one tMin, idle lanes taking subtrees of busy lanes): the same answers, ray for ray
+        occ_shared, _ = dev.trace_rays(probe, any_hit=True, uniform_tmin=True)
+        assert np.array_equal(occ_shared, occ)
         probe[:, 7] = th * (1 - 1e-3)  # nothing is nearer than the nearest hit
         occ, _ = dev.trace_rays(probe, any_hit=True)
         assert (occ != 0).mean() <= 1e-5
+        # ... and with a wavefront's lanes mostly idle: 7 rays in 8 end at once (tMax just beyond tMin), so nearly every
+        # visit of the others hands subtrees over; those others are cut short at random: occluded and free rays mixed
+        sparse = probe.copy()
+        sparse[:, 7] = th * rng.uniform(0.2, 1.8, th.shape[0]).astype(np.float32)
+        sparse[np.arange(sparse.shape[0]) % 8 != 0, 7] = 0.0101
+        a, _ = dev.trace_rays(sparse, any_hit=True)
+        b, _ = dev.trace_rays(sparse, any_hit=True, uniform_tmin=True)
+        assert 0.2 < a[::8].mean() < 0.8 and np.array_equal(a, b)
         probe[:, 6] = th * (1 + 1e-3)  # beyond the nearest hit: whatever a nearest-hit ray finds in the same interval
         probe[:, 7] = 1e30
         occ, _ = dev.trace_rays(probe, any_hit=True)
