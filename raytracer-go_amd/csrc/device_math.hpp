@@ -777,7 +777,7 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
     // ray.  work_of = the lane whose ray this lane is walking for (itself at first); hit_rays = the rays (by their own
     // lane) known to be occluded, wave-uniform: every lane that walks for such a ray stops at the next shape loop.
     // Config 3: 13.6 -> 10.6 walk iterations per round of 64 rays, lane utilisation of the block visits 0.59 -> 0.81,
-    // 6 % more block visits (subtrees walked for rays that another lane finds occluded) — and k_shadow 271 -> 266 ms:
+    // 6 % more block visits (subtrees walked for rays that another lane finds occluded) — and k_shadow 271 -> 262 ms:
     // a visit with few lanes is cheap on the memory side, so the iterations saved were the cheap ones.  Giving the
     // OLDEST entry (the farthest, largest subtree) instead of the newest: 277 ms, most of that work is never needed.
     constexpr bool kSteal = SAME_TMIN;
@@ -904,15 +904,18 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const bool take = idle && idle_rank < n_take;
                 const uint32_t got = take ? flag[idle_rank] : (uint32_t)lane;
+                // the giver's ray comes over by cross-lane reads, its derived values (1 / d, o / d, signs) too: those
+                // reads go through the LDS pipe, which has room, where recomputing them would cost VALU issue slots; a
+                // lane that takes nothing reads from itself, so no lane needs a select
                 const int from = (int)(got & 63u);
-                const f3 o2 = mk3(__shfl(o.x, from), __shfl(o.y, from), __shfl(o.z, from));
-                const f3 d2 = mk3(__shfl(d.x, from), __shfl(d.y, from), __shfl(d.z, from));
-                const float tmax2 = __shfl(tmax, from);
-                const int of2 = __shfl(work_of, from);
-                if (take) {
-                    o = o2; d = d2; tmax = tmax2; r = make_qray(o2, d2);
-                    work_of = of2; cur = got >> 6; sp = 0; walking = true; occ = false;
-                }
+                o = mk3(__shfl(o.x, from), __shfl(o.y, from), __shfl(o.z, from));
+                d = mk3(__shfl(d.x, from), __shfl(d.y, from), __shfl(d.z, from));
+                r.inv = mk3(__shfl(r.inv.x, from), __shfl(r.inv.y, from), __shfl(r.inv.z, from));
+                r.oi = mk3(__shfl(r.oi.x, from), __shfl(r.oi.y, from), __shfl(r.oi.z, from));
+                r.sign = (uint32_t)__shfl((int)r.sign, from);
+                tmax = __shfl(tmax, from);
+                work_of = __shfl(work_of, from);
+                if (take) { cur = got >> 6; sp = 0; walking = true; occ = false; }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
