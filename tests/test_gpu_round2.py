@@ -239,7 +239,7 @@ def test_pair_beams_decide_the_same_rays(backend, rt, scenes, c1, gold_dir, monk
 def test_pair_beams_on_random_scenes(backend, rt, monkeypatch):
     """Beams and the resumed walks against plain per-ray tracing (RTGO_BEAM=0) on seeded random scenes: triangle
     soup + spheres around the origin or 1000 units away from it, point and spot lights in the open, among the shapes
-    and right above a surface, 1 / 5 / 16 repetitions, a mirror so that later bounces shade too.  The accumulation
+    and right above a surface, 1 to 130 repetitions, a mirror so that later bounces shade too.  The accumulation
     buffers and the counters must be identical."""
     api = rt
     total_beam = 0
@@ -268,7 +268,7 @@ def test_pair_beams_on_random_scenes(backend, rt, monkeypatch):
                                  InverseSquareLawDecayFactor=0.5),  # among the triangles
                   api.SpotLight(ColorFrac=api.Vec(0.8, 0.9, 1), Position=V(-5, 0.3, -4), LightIntensity=40, SpecularLightIntensity=10,
                                 LookAt=V(0, 1, 0), Angle=35.0, InverseSquareLawDecayFactor=0.3)]  # 0.3 above the floor
-        reps = (1, 5, 16)[seed % 3]
+        reps = (1, 5, 16, 70, 3, 130)[seed % 6]  # 70, 130: more repetitions than the 64 lanes of a pair's group
         spec = api.ImageSpec(160, 100, 3, 6, reps, 16, api.Dijkstra)
         scene = api.Scene(V(0, 3.5, -9), V(0, 1.5, 0), api.Vec(0, 1, 0), V(0, 1.5, 0), 0.02, 50.0, shapes, lights)
         with backend.DeviceScene(scene) as dev:
