@@ -95,6 +95,7 @@ struct DScene {
     const DMaterial* materials;
     const DTexture* textures;
     const DLight* lights;
+    const DLight* pos_lights;  // the positional (point and spot) lights of `lights`, in the same order
     int n_lights, n_pos_lights;
     uint32_t root_ref;
 };

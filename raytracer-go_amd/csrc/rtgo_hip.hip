@@ -64,23 +64,27 @@ struct Batch {
     int W, H;
     int tile, tiles_x;         // square tiles of `tile` pixels (multiple of 8), row-major tile grid
     int rank, world, by_tiles; // by_tiles: this rank owns tiles k with k % world == rank
-    long long lp0;             // first local pixel of the batch
+    uint32_t tj0;              // first local tile of the batch (a batch starts on a tile; a frame has fewer than 2^32 tiles)
     int npix, ns, s0;          // local pixels, samples per pixel in this batch, first sample index
     int max_depth, reps;
     uint32_t k0, k1;           // Philox key
 };
 
-// local pixel -> (column x, output row); false when the tile cell lies outside the image
-RT_DEV bool pixel_of(const Batch& B, long long lp, int* x, int* row) {
-    const int tt = B.tile * B.tile;
-    const long long tj = lp / tt;
-    const int w = (int)(lp - tj * tt);
-    const long long k = B.by_tiles ? tj * B.world + B.rank : tj;
-    const int tx = (int)(k % B.tiles_x), ty = (int)(k / B.tiles_x);
-    const int sub_per_row = B.tile >> 3;
-    const int b = w >> 6, i = w & 63;  // 8x8 sub-blocks keep a wavefront's pixels together
-    *x = tx * B.tile + (b % sub_per_row) * 8 + (i & 7);
-    *row = ty * B.tile + (b / sub_per_row) * 8 + (i >> 3);
+// pixel of the batch (counted from its first tile) -> (column x, output row); false when the tile cell lies outside
+// the image.  All in 32 bits: a batch has at most 2^30 pixels and a frame fewer than 2^32 tiles (64-bit divisions were
+// most of k_raygen's instructions).
+RT_DEV bool pixel_of(const Batch& B, uint32_t lpl, int* x, int* row) {
+    const uint32_t tt = (uint32_t)(B.tile * B.tile);
+    const uint32_t tjl = lpl / tt;
+    const uint32_t w = lpl - tjl * tt;
+    const uint32_t tj = B.tj0 + tjl;
+    const uint32_t k = B.by_tiles ? tj * (uint32_t)B.world + (uint32_t)B.rank : tj;
+    const uint32_t ty = k / (uint32_t)B.tiles_x, tx = k - ty * (uint32_t)B.tiles_x;
+    const uint32_t sub_per_row = (uint32_t)B.tile >> 3;
+    const uint32_t b = w >> 6, i = w & 63u;  // 8x8 sub-blocks keep a wavefront's pixels together
+    const uint32_t by = b / sub_per_row, bx = b - by * sub_per_row;
+    *x = (int)(tx * (uint32_t)B.tile + bx * 8u + (i & 7u));
+    *row = (int)(ty * (uint32_t)B.tile + by * 8u + (i >> 3));
     return *x < B.W && *row < B.H;
 }
 
@@ -93,7 +97,8 @@ struct Work {
     uint32_t* queue[2];
     uint32_t* phong_queue;
     uint32_t* vis;   // visible-repetition count per (phong hit, positional light)
-    uint32_t* pairs; // (hit, light) pairs whose shading term is not exactly zero: light * n_hits + hit, light-major
+    uint32_t* pairs; // (hit, light) pairs whose shading term is not exactly zero: hit << light_shift | light, light-major
+    uint32_t light_shift;  // bits of a pair that hold the positional light's number (2^light_shift >= their count): no division per pair
     uint32_t* pair_seg;    // the same before compaction: light l's hits at [l * n_hits, l * n_hits + light_count[l])
     uint32_t* light_count; // [0, L) pairs per positional light, [L, 2L) their exclusive prefix sums, [2L] pairs k_pair_beam passes on
     uint32_t* counters;  // per batch: [0..D] ray-queue sizes per bounce, [D+1..2D] phong-queue sizes,
@@ -127,6 +132,34 @@ RT_DEV uint32_t block_push(uint32_t* counter, bool pred) {
     return at;
 }
 
+// block_push for up to N queues at once (k_phong_pairs: one queue per positional light): the same three barriers
+// serve all of them, and thread q of the block does queue q's atomic.
+template <int N>
+RT_DEV void block_push_multi(uint32_t* counters, int n, const bool (&pred)[N], uint32_t (&at)[N]) {
+    __shared__ uint32_t s_cnt[N][kBlock / 64 + 1];
+    const int lane = (int)__lane_id(), wave = (int)(threadIdx.x >> 6);
+    unsigned long long mask[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        mask[q] = __ballot(q < n && pred[q]);
+        if (lane == 0) s_cnt[q][wave] = (uint32_t)__popcll(mask[q]);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n) {
+        uint32_t total = 0;
+        for (int w = 0; w < kBlock / 64; ++w) total += s_cnt[threadIdx.x][w];
+        s_cnt[threadIdx.x][kBlock / 64] = total ? atomicAdd(counters + threadIdx.x, total) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        uint32_t a = s_cnt[q][kBlock / 64];
+        for (int w = 0; w < wave; ++w) a += s_cnt[q][w];
+        at[q] = a + (uint32_t)__popcll(mask[q] & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();  // s_cnt is reused by the next call
+}
+
 // raytracer.go:114-116 + camera.go:37-55
 RT_DEV void camera_ray(const DCamera& cam, int W, int H, int i, int j, const RngKey& key, f3* o, f3* d) {
     const u4 aa = draw(key, 0, P_AA, 0, 0);
@@ -145,14 +178,14 @@ RT_DEV void camera_ray(const DCamera& cam, int W, int H, int i, int j, const Rng
 }
 
 __global__ __launch_bounds__(kBlock) void k_raygen(Batch B, DCamera cam, Work Wk) {
-    const long long slot = (long long)blockIdx.x * kBlock + threadIdx.x;
-    const long long total = (long long)B.npix * B.ns;
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;  // (a batch holds at most 2^30 paths: plan_render)
+    const uint32_t total = (uint32_t)B.npix * (uint32_t)B.ns;
     bool valid = slot < total;
     int x = 0, row = 0, smp = 0;
     if (valid) {
-        const long long lpl = slot / B.ns;
-        smp = B.s0 + (int)(slot - lpl * B.ns);
-        valid = pixel_of(B, B.lp0 + lpl, &x, &row);
+        const uint32_t lpl = slot / (uint32_t)B.ns;
+        smp = B.s0 + (int)(slot - lpl * (uint32_t)B.ns);
+        valid = pixel_of(B, lpl, &x, &row);
     }
     if (valid) {
         const RngKey key{B.k0, B.k1, (uint32_t)(row * B.W + x), (uint32_t)smp};
@@ -361,18 +394,25 @@ __global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, const
     const bool live = hit_i < n_hits;
     PhongHit h{};
     if (live) h = load_phong_hit(S, Wk, Wk.phong_queue[hit_i]);
-    uint32_t lp = 0;
-    for (int q = 0; q < S.n_lights; ++q) {  // uniform trip count: block_push is a block-wide operation
-        if (S.lights[q].kind == RT_LIGHT_AMBIENT) continue;
-        bool keep = false;
-        if (live) {
-            const f3 comb = phong_term(S.lights[q], h.m, h.mc, h.p, h.nrm, h.d);
-            keep = !(comb.x == 0.0f && comb.y == 0.0f && comb.z == 0.0f) && !surely_outside_cone(S.lights[q], h.p);
-            Wk.vis[(size_t)hit_i * S.n_pos_lights + lp] = 0u;
+    constexpr int kAtOnce = 4;  // lights per round of block-wide pushes (uniform trip counts: every thread of the block takes part)
+    for (int lp0 = 0; lp0 < S.n_pos_lights; lp0 += kAtOnce) {
+        const int n = S.n_pos_lights - lp0 < kAtOnce ? S.n_pos_lights - lp0 : kAtOnce;
+        bool keep[kAtOnce];
+#pragma unroll
+        for (int k = 0; k < kAtOnce; ++k) {
+            keep[k] = false;
+            if (k < n && live) {
+                const DLight& L = S.pos_lights[lp0 + k];
+                const f3 comb = phong_term(L, h.m, h.mc, h.p, h.nrm, h.d);
+                keep[k] = !(comb.x == 0.0f && comb.y == 0.0f && comb.z == 0.0f) && !surely_outside_cone(L, h.p);
+                Wk.vis[(size_t)hit_i * S.n_pos_lights + (lp0 + k)] = 0u;
+            }
         }
-        const uint32_t at = block_push(&Wk.light_count[lp], keep);
-        if (keep) Wk.pair_seg[(size_t)lp * n_hits + at] = hit_i;
-        ++lp;
+        uint32_t at[kAtOnce];
+        block_push_multi<kAtOnce>(Wk.light_count + lp0, n, keep, at);
+#pragma unroll
+        for (int k = 0; k < kAtOnce; ++k)
+            if (keep[k]) Wk.pair_seg[(size_t)(lp0 + k) * n_hits + at[k]] = hit_i;
     }
 }
 // exclusive prefix sums of the per-light pair counts; the total is the pair-queue length k_shadow reads
@@ -387,12 +427,11 @@ __global__ void k_pair_offsets(Work Wk, int n_pos_lights, uint32_t* pair_counter
     Wk.light_count[2 * n_pos_lights] = 0u;  // length of the queue k_pair_beam builds
 }
 __global__ __launch_bounds__(kBlock) void k_pair_compact(Work Wk, const uint32_t* n_hits_ptr, int n_pos_lights) {
-    const unsigned long long idx = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    // grid: x over the hits, y over the positional lights (a light per grid row, no division per element)
     const uint32_t n_hits = *n_hits_ptr;
-    if (idx >= (unsigned long long)n_hits * n_pos_lights) return;
-    const uint32_t l = (uint32_t)(idx / n_hits);
-    const uint32_t j = (uint32_t)(idx - (unsigned long long)l * n_hits);
-    if (j < Wk.light_count[l]) Wk.pairs[Wk.light_count[n_pos_lights + l] + j] = l * n_hits + Wk.pair_seg[idx];
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    for (uint32_t l = blockIdx.y; l < (uint32_t)n_pos_lights; l += gridDim.y)
+        if (j < Wk.light_count[l]) Wk.pairs[Wk.light_count[n_pos_lights + l] + j] = (Wk.pair_seg[(size_t)l * n_hits + j] << Wk.light_shift) | l;
 }
 
 // One lane per queued (hit, light) pair: ONE conservative walk for all of the pair's shadow rays (device_math.hpp
@@ -404,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_compact(Work Wk, const uint32_t
 #endif
 __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S, Batch B, Work Wk, const uint32_t* n_hits_ptr, const uint32_t* pair_counter) {
     __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
-    const uint32_t n_hits = *n_hits_ptr;
+    (void)n_hits_ptr;
     const uint32_t n_pairs = *pair_counter;
     const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlock;
@@ -420,15 +459,12 @@ __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S,
         Beam bm{};
         if (live) {
             hl = Wk.pairs[i];
-            lp = hl / n_hits;
-            hit_i = hl - lp * n_hits;
+            lp = hl & ((1u << Wk.light_shift) - 1u);
+            hit_i = hl >> Wk.light_shift;
             const uint32_t slot = Wk.phong_queue[hit_i];
             const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
             const f3 p = add3(mk3(ro.x, ro.y, ro.z), scale3(ro.w, mk3(rdv.x, rdv.y, rdv.z)));
-            int q = 0;  // positional light #lp
-            for (int seen = -1; q < S.n_lights; ++q)
-                if (S.lights[q].kind != RT_LIGHT_AMBIENT && ++seen == (int)lp) break;
-            const DLight& L = S.lights[q];
+            const DLight& L = S.pos_lights[lp];
             judge = surely_inside_cone(L, p);
             if (judge) bm = make_beam(p, ld3(L.pos), 0.25f * 1.0001f + 1e-5f, 0.01f);
         }
@@ -463,7 +499,7 @@ template <bool MANY_REPS>  // more than 64 repetitions: a lane runs several of a
 __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, Batch B, Work Wk, const uint32_t* n_hits_ptr, int bounce,
                                                    int group, int group_shift, const uint32_t* pairs, const uint32_t* pair_counter, const uint32_t* beam_state) {
     __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
-    const uint32_t n_hits = *n_hits_ptr;
+    (void)n_hits_ptr;
     __shared__ uint32_t s_wave[(kBlock / 64) * 128];
     const uint32_t gtid = xcd_block() * kBlock + threadIdx.x;
     const uint32_t gstride = gridDim.x * kBlock;
@@ -500,28 +536,24 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
                 // consecutive hits (neighbouring pixels / samples) towards the SAME light, so all 64 shadow rays
                 // are nearly parallel
                 const uint32_t hl = pairs[pi];
-                const uint32_t lp = hl / n_hits;
-                const uint32_t hit_i = hl - lp * n_hits;
+                const uint32_t lp = hl & ((1u << Wk.light_shift) - 1u);
+                const uint32_t hit_i = hl >> Wk.light_shift;
                 const uint32_t slot = Wk.phong_queue[hit_i];
                 const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
                 p = add3(mk3(ro.x, ro.y, ro.z), scale3(ro.w, mk3(rdv.x, rdv.y, rdv.z)));
                 const uint2 pk = Wk.path_key[slot];
                 const RngKey key{B.k0, B.k1, pk.x, pk.y};
-                int q = 0;  // positional light #lp
-                for (int seen = -1; q < S.n_lights; ++q)
-                    if (S.lights[q].kind != RT_LIGHT_AMBIENT && ++seen == (int)lp) break;
-                const DLight& L = S.lights[q];
+                const DLight& L = S.pos_lights[lp];
                 const f3 jit = scale3(0.25f, random_in_unit_sphere(key, (uint32_t)bounce, P_SHADOW, lp * (uint32_t)B.reps + rep));
                 const f3 shifted = add3(ld3(L.pos), jit);  // light.go:94 / :123
-                bool in_cone = true;
-                if (L.kind == RT_LIGHT_SPOT)  // light.go:126-130 as cos(angle) >= cos(Angle)
-                    in_cone = dot3(ld3(L.look_dir), unit3(sub3(p, shifted))) >= L.cos_angle;
-                if (in_cone) {
-                    traced = true;
-                    const f3 ld = sub3(shifted, p);  // doesReachLight, light.go:141-160
-                    dist = norm3(ld);
-                    dir = scale3(1.0f / dist, ld);
-                }
+                const f3 ld = sub3(shifted, p);  // doesReachLight, light.go:141-160
+                dist = norm3(ld);
+                dir = scale3(1.0f / dist, ld);
+                // light.go:126-130 as cos(angle) >= cos(Angle).  Unit(p - L') is -dir bit for bit (x - y = -(y - x), so the
+                // same norm and the same quotient; only a zero component's sign differs, which a dot product does not see;
+                // p = L' gives NaN either way), and a dot product with -dir is the negated dot product with dir: one
+                // square root and one division per ray instead of two of each
+                traced = L.kind != RT_LIGHT_SPOT || -dot3(ld3(L.look_dir), dir) >= L.cos_angle;
             }
             launched += (unsigned long long)__popcll(__ballot(traced));
             RT_PROF_POINT(2);  // shadow-ray rounds
@@ -557,8 +589,7 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
             const uint32_t pj = it * pairs_per_round + mine;
             if (pj < n_pairs) {
                 const uint32_t hl = pairs[pj];
-                const uint32_t lp = hl / n_hits;
-                Wk.vis[(size_t)(hl - lp * n_hits) * S.n_pos_lights + lp] = count;
+                Wk.vis[(size_t)(hl >> Wk.light_shift) * S.n_pos_lights + (hl & ((1u << Wk.light_shift) - 1u))] = count;
             }
         }
     }
@@ -598,7 +629,7 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(Batch B, Work Wk, float* 
     const long long lpl = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (lpl >= B.npix) return;
     int x, row;
-    if (!pixel_of(B, B.lp0 + lpl, &x, &row)) return;
+    if (!pixel_of(B, (uint32_t)lpl, &x, &row)) return;
     float sx = 0.0f, sy = 0.0f, sz = 0.0f;
     const float4* r = Wk.rad + lpl * B.ns;
     for (int k = 0; k < B.ns; ++k) { const float4 v = r[k]; sx += v.x; sy += v.y; sz += v.z; }
@@ -1226,6 +1257,8 @@ static int build_host_scene(const rt_scene_desc* desc, HostScene* h, Laps& lap) 
         if (l.kind != RT_LIGHT_AMBIENT) ++n_pos;
     }
     h->n_pos = n_pos;
+    for (int64_t i = 0; i < desc->n_lights; ++i)  // the positional lights once more, in order: pair -> light without a search
+        if (lights[(size_t)i].kind != RT_LIGHT_AMBIENT) lights.push_back(lights[(size_t)i]);
     lap("tables");
     return RT_OK;
 }
@@ -1329,6 +1362,7 @@ static int finish_scene(const rt_scene_desc* desc, const HostScene& h, rt_scene*
     s->d.recs = (const float4*)s->d_recs; s->d.qblocks = (const uint4*)s->d_qblocks; s->d.prims = (const float4*)s->d_prims; s->d.tprims = (const float4*)s->d_tprims; s->d.prim_ids = (const int*)s->d_prim_ids; s->d.block_first = (const uint32_t*)s->d_block_first; s->d.block_box = (const float4*)s->d_block_box;
     s->d.materials = (const DMaterial*)s->d_mats; s->d.textures = (const DTexture*)s->d_texs;
     s->d.lights = (const DLight*)s->d_lights;
+    s->d.pos_lights = s->d.lights + desc->n_lights + 1;
     s->d.n_lights = (int)desc->n_lights; s->d.n_pos_lights = h.n_pos; s->d.root_ref = h.flat.root_ref;
     {  // the lanes' events, streams and pinned counters: made by a thread of their own since the tree build began
         const std::pair<hipError_t, const char*> made = lane_setup->get();
@@ -1403,6 +1437,11 @@ int rt_scene_get_info(const rt_scene* s, rt_scene_info* out) {
 }
 
 // What a render call needs besides the scene: its share of the frame, as batches of (pixel, sample) paths.
+static int light_shift_of(int n_pos_lights) {  // bits for a positional light's number
+    int b = 0;
+    while ((1 << b) < n_pos_lights) ++b;
+    return b;
+}
 struct RenderPlan {
     rt_partition part;
     int tile, tiles_x, sA, sB, ns_max, group, group_shift;
@@ -1467,6 +1506,7 @@ static int plan_render(const rt_scene* s, const rt_image_spec* spec, const rt_pa
     const int64_t pair_cap = (((int64_t)1 << 32) - 1 - (int64_t)kMaxGridBlocks * kBlock) / std::max(1, s->d.n_pos_lights);
     if (pair_cap < (int64_t)tile * tile) return fail(RT_ERR_LIMIT, "too many positional lights for one tile of paths; use a smaller tile_size");
     if (max_paths > pair_cap) max_paths = pair_cap;
+    if (max_paths > ((int64_t)1 << (32 - light_shift_of(s->d.n_pos_lights)))) max_paths = (int64_t)1 << (32 - light_shift_of(s->d.n_pos_lights));  // hit << light_shift | light
     P->ns_max = (int)std::min<long long>(P->sB - P->sA, std::min<long long>(64, max_paths / ((long long)tile * tile)));
     P->pix_per_batch = std::max<long long>(1, max_paths / P->ns_max / ((long long)tile * tile)) * tile * tile;
     // a share of fewer batches than lanes is cut into as many batches as there are lanes, as long as a batch keeps
@@ -1511,6 +1551,7 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
     // what a pair's rays resume from: 48 bytes per (path, light) of a batch, in a buffer of the lane's own that only
     // calls which walk pair beams make (and only entry points that may allocate; without it the rays start at the root)
     wk.beam_state = nullptr;
+    wk.light_shift = (uint32_t)light_shift_of(L);
     if (beams && resume_on && may_create_events && L > 0 && reps > 0) {
         const unsigned long long need = (unsigned long long)P.batch_paths * (unsigned long long)L * kResumeWords * sizeof(uint32_t);
         if (need <= (4ull << 30)) {  // (many lights: the rays then start at the root)
@@ -1542,7 +1583,7 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
             Batch B{};
             B.W = W; B.H = H; B.tile = P.tile; B.tiles_x = P.tiles_x;
             B.rank = P.part.rank; B.world = P.part.world_size; B.by_tiles = P.by_tiles ? 1 : 0;
-            B.lp0 = lp0; B.npix = (int)std::min<long long>(P.pix_per_batch, P.n_local_pixels - lp0);
+            B.tj0 = (uint32_t)(lp0 / ((long long)P.tile * P.tile)); B.npix = (int)std::min<long long>(P.pix_per_batch, P.n_local_pixels - lp0);
             B.ns = ns; B.s0 = s0; B.max_depth = D; B.reps = reps;
             B.k0 = (uint32_t)P.part.seed; B.k1 = (uint32_t)(P.part.seed >> 32);
             const long long slots = (long long)B.npix * ns;
@@ -1569,7 +1610,7 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
                     HIP_TRY(hipMemsetAsync(wk.light_count, 0, (size_t)L * sizeof(uint32_t), stream));
                     hipLaunchKernelGGL(k_phong_pairs, dim3((bound + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, wk, n_phong);
                     hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(64), 0, stream, wk, L, pair_counter);
-                    hipLaunchKernelGGL(k_pair_compact, dim3((unsigned)((n_pairs + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, wk, n_phong, L);
+                    hipLaunchKernelGGL(k_pair_compact, dim3((bound + kBlock - 1) / kBlock, (unsigned)std::min(L, 65535)), dim3(kBlock), 0, stream, wk, n_phong, L);
                     if (reps > 0) {
                         const uint32_t* queue = wk.pairs;
                         const uint32_t* queue_len = pair_counter;
