@@ -88,6 +88,7 @@ RT_DEV bool pixel_of(const Batch& B, uint32_t lpl, int* x, int* row) {
     return *x < B.W && *row < B.H;
 }
 
+constexpr int kSubCounters = 64;
 struct Work {
     float4* ray_o;   // {origin.xyz, hit t}
     float4* ray_d;   // {direction.xyz, bits of hit shape index (-1 = miss)}
@@ -103,10 +104,12 @@ struct Work {
     uint32_t* light_count; // [0, L) pairs per positional light, [L, 2L) their exclusive prefix sums, [2L] pairs k_pair_beam passes on
     uint32_t* counters;  // per batch: [0..D] ray-queue sizes per bounce, [D+1..2D] phong-queue sizes,
                          // [2D+4..3D+3] pair-queue sizes per bounce
-    unsigned long long* frame_counters;  // per call: [0] shadow rays traced, [1] shadow rays decided by a pair's beam walk
+    unsigned long long* frame_counters;  // per call: [0] shadow rays traced, [1] shadow rays decided by a pair's beam walk: the sums
+                                         // (k_sum_counters) of [2, 2 + kSubCounters) and of the kSubCounters words after those, to
+                                         // which the wavefronts add (one address takes an atomic every 11 ns, 65,536 per launch)
     uint32_t* overflow;  // traversal stack spill
     uint32_t overflow_stride;
-    uint32_t* beam_state;  // per pair of the queue k_pair_beam builds: kResumeWords words its rays resume from (nullptr: none kept)
+    uint32_t* beam_state;  // per (phong hit, positional light), like vis: kResumeWords words the pair's rays resume from (nullptr: none kept)
 };
 
 // Queue compaction: ballot + popcount prefix inside a wavefront, the wavefronts' counts combined through
@@ -160,6 +163,39 @@ RT_DEV void block_push_multi(uint32_t* counters, int n, const bool (&pred)[N], u
     __syncthreads();  // s_cnt is reused by the next call
 }
 
+// block_push for K elements per thread (element k of thread t is item (k * kBlock + t) of the block): ONE atomic
+// per block and queue for all K * kBlock of them, and the queue keeps the items' order.  A queue counter is a single
+// address, and atomics on one address go through at about 11 ns each whatever else the GPU does: with one per
+// 256 items they took most of the time of k_raygen, k_shade and k_phong_pairs.
+// Q queues at once (bit q of pred[k]: element k goes to queue q); at[k][q] is only meaningful where that bit is set.
+template <int Q, int K>
+RT_DEV void block_push_qk(uint32_t* const* counters, int n_queues, const uint32_t (&pred)[K], uint32_t (&at)[K][Q]) {
+    __shared__ uint32_t s_cnt[Q][K * (kBlock / 64) + 1];
+    const int lane = (int)__lane_id(), wave = (int)(threadIdx.x >> 6);
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const unsigned long long m = __ballot(((pred[k] >> q) & 1u) != 0u);
+            if (lane == 0) s_cnt[q][k * (kBlock / 64) + wave] = (uint32_t)__popcll(m);
+        }
+    __syncthreads();
+    if ((int)threadIdx.x < n_queues && (int)threadIdx.x < Q) {  // thread q: exclusive prefix sums of queue q's counts, then its atomic
+        uint32_t run = 0;
+        for (int j = 0; j < K * (kBlock / 64); ++j) { const uint32_t c = s_cnt[threadIdx.x][j]; s_cnt[threadIdx.x][j] = run; run += c; }
+        s_cnt[threadIdx.x][K * (kBlock / 64)] = run ? atomicAdd(counters[threadIdx.x], run) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const unsigned long long m = __ballot(((pred[k] >> q) & 1u) != 0u);
+            at[k][q] = s_cnt[q][K * (kBlock / 64)] + s_cnt[q][k * (kBlock / 64) + wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        }
+    __syncthreads();  // s_cnt is reused by the next call
+}
+
 // raytracer.go:114-116 + camera.go:37-55
 RT_DEV void camera_ray(const DCamera& cam, int W, int H, int i, int j, const RngKey& key, f3* o, f3* d) {
     const u4 aa = draw(key, 0, P_AA, 0, 0);
@@ -177,28 +213,40 @@ RT_DEV void camera_ray(const DCamera& cam, int W, int H, int i, int j, const Rng
     *d = unit3(sub3(sub3(add3(add3(ld3(cam.ll), scale3(u, ld3(cam.hor))), scale3(v, ld3(cam.ver))), ld3(cam.origin)), offset));
 }
 
+constexpr int kPerThread = 4;  // elements per thread in the kernels that fill a queue (block_push_qk)
 __global__ __launch_bounds__(kBlock) void k_raygen(Batch B, DCamera cam, Work Wk) {
-    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;  // (a batch holds at most 2^30 paths: plan_render)
-    const uint32_t total = (uint32_t)B.npix * (uint32_t)B.ns;
-    bool valid = slot < total;
-    int x = 0, row = 0, smp = 0;
-    if (valid) {
-        const uint32_t lpl = slot / (uint32_t)B.ns;
-        smp = B.s0 + (int)(slot - lpl * (uint32_t)B.ns);
-        valid = pixel_of(B, lpl, &x, &row);
+    const uint32_t total = (uint32_t)B.npix * (uint32_t)B.ns;  // (a batch holds at most 2^30 paths: plan_render)
+    uint32_t valid[kPerThread];
+    uint32_t pixel[kPerThread];  // row * W + x
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {  // which of the block's slots are paths: only the pixel arithmetic
+        const uint32_t slot = (blockIdx.x * kPerThread + k) * kBlock + threadIdx.x;
+        valid[k] = 0u; pixel[k] = 0u;
+        if (slot < total) {
+            int x = 0, row = 0;
+            if (pixel_of(B, slot / (uint32_t)B.ns, &x, &row)) { valid[k] = 1u; pixel[k] = (uint32_t)(row * B.W + x); }
+            Wk.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
     }
-    if (valid) {
-        const RngKey key{B.k0, B.k1, (uint32_t)(row * B.W + x), (uint32_t)smp};
+    uint32_t at[kPerThread][1];
+    uint32_t* const counters[1] = {&Wk.counters[0]};
+    block_push_qk<1, kPerThread>(counters, 1, valid, at);
+#pragma unroll 1
+    for (int k = 0; k < kPerThread; ++k) {
+        if (!valid[k]) continue;
+        const uint32_t slot = (blockIdx.x * kPerThread + k) * kBlock + threadIdx.x;
+        const uint32_t lpl = slot / (uint32_t)B.ns;
+        const int smp = B.s0 + (int)(slot - lpl * (uint32_t)B.ns);
+        const int row = (int)(pixel[k] / (uint32_t)B.W), x = (int)(pixel[k] - (uint32_t)row * (uint32_t)B.W);
+        const RngKey key{B.k0, B.k1, pixel[k], (uint32_t)smp};
         Wk.path_key[slot] = make_uint2(key.pixel, key.sample);
         f3 o, d;
         camera_ray(cam, B.W, B.H, x, B.H - 1 - row, key, &o, &d);
         Wk.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.0f);
         Wk.ray_d[slot] = make_float4(d.x, d.y, d.z, __int_as_float(-1));
         Wk.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        Wk.queue[0][at[k][0]] = slot;
     }
-    if (slot < total) Wk.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const uint32_t at = block_push(&Wk.counters[0], valid);
-    if (valid) Wk.queue[0][at] = (uint32_t)slot;
 }
 
 // Workgroups go to the 8 XCDs round-robin and every XCD has an L2 of its own: block b works on virtual
@@ -264,9 +312,15 @@ RT_DEV Scattered scatter_specular(const DMaterial& m, f3 d, f3 p, f3 nrm, const 
 // color() (raytracer.go:135-162) one bounce at a time + Standard/Metal/Dielectric scatter
 __global__ __launch_bounds__(kBlock) void k_shade(DScene S, Batch B, Work Wk, const uint32_t* queue, const uint32_t* n_ptr,
                                                   uint32_t* next_queue, int bounce) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    // kPerThread queue entries per thread, then ONE push per block and queue (block_push_qk); what an entry adds to
+    // which queue waits in LDS meanwhile: its path slot (below 2^30) | goes on << 30 | PhongBlinn hit << 31
+    __shared__ uint32_t s_item[kPerThread][kBlock];
     const uint32_t n = *n_ptr;
-    if (blockIdx.x * kBlock >= n) return;  // whole block beyond the queue (the grid covers an upper bound)
+    const uint32_t first = blockIdx.x * (kBlock * kPerThread);
+    if (first >= n) return;  // whole block beyond the queue (the grid covers an upper bound)
+#pragma unroll 1
+    for (int k = 0; k < kPerThread; ++k) {
+    const uint32_t i = first + (uint32_t)k * kBlock + threadIdx.x;
     bool cont = false, phong = false;
     uint32_t slot = 0;
     if (i < n) {
@@ -305,10 +359,19 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene S, Batch B, Work Wk, co
     }
     // a ray scattered at the last allowed depth can only return black (raytracer.go:145)
     cont = cont && (bounce + 1 < B.max_depth);
-    const uint32_t at = block_push(&Wk.counters[bounce + 1], cont);
-    if (cont) next_queue[at] = slot;
-    const uint32_t pat = block_push(&Wk.counters[B.max_depth + 1 + bounce], phong);
-    if (phong) Wk.phong_queue[pat] = slot;
+    s_item[k][threadIdx.x] = slot | (cont ? 1u << 30 : 0u) | (phong ? 1u << 31 : 0u);
+    }
+    uint32_t pred[kPerThread], at[kPerThread][2];
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) pred[k] = s_item[k][threadIdx.x] >> 30;  // (a thread reads what it wrote itself)
+    uint32_t* const counters[2] = {&Wk.counters[bounce + 1], &Wk.counters[B.max_depth + 1 + bounce]};
+    block_push_qk<2, kPerThread>(counters, 2, pred, at);
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+        const uint32_t slot = s_item[k][threadIdx.x] & 0x3fffffffu;
+        if (pred[k] & 1u) next_queue[at[k][0]] = slot;
+        if (pred[k] & 2u) Wk.phong_queue[at[k][1]] = slot;
+    }
 }
 
 // What one visible repetition of light L adds at a PhongBlinn hit (material.go:83-119).  The light position
@@ -388,31 +451,42 @@ RT_DEV bool surely_inside_cone(const DLight& L, const f3& p) {
 // (segment l of pair_seg), so that the queue k_pair_compact builds from the segments is light-major.
 // Every pair's visible-repetition count starts at 0 here.
 __global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, const uint32_t* n_hits_ptr) {
-    const uint32_t hit_i = blockIdx.x * kBlock + threadIdx.x;
+    // kPerThread hits per thread and up to kAtOnce lights per round, then ONE push per block and light
+    // (block_push_qk; uniform trip counts: every thread of the block takes part)
+    constexpr int kAtOnce = 4;
+    __shared__ uint32_t s_keep[kPerThread][kBlock];  // bit q: the hit's pair with light lp0 + q is kept
     const uint32_t n_hits = *n_hits_ptr;
-    if (blockIdx.x * kBlock >= n_hits) return;
-    const bool live = hit_i < n_hits;
-    PhongHit h{};
-    if (live) h = load_phong_hit(S, Wk, Wk.phong_queue[hit_i]);
-    constexpr int kAtOnce = 4;  // lights per round of block-wide pushes (uniform trip counts: every thread of the block takes part)
+    const uint32_t first = blockIdx.x * (kBlock * kPerThread);
+    if (first >= n_hits) return;
     for (int lp0 = 0; lp0 < S.n_pos_lights; lp0 += kAtOnce) {
         const int n = S.n_pos_lights - lp0 < kAtOnce ? S.n_pos_lights - lp0 : kAtOnce;
-        bool keep[kAtOnce];
-#pragma unroll
-        for (int k = 0; k < kAtOnce; ++k) {
-            keep[k] = false;
-            if (k < n && live) {
-                const DLight& L = S.pos_lights[lp0 + k];
-                const f3 comb = phong_term(L, h.m, h.mc, h.p, h.nrm, h.d);
-                keep[k] = !(comb.x == 0.0f && comb.y == 0.0f && comb.z == 0.0f) && !surely_outside_cone(L, h.p);
-                Wk.vis[(size_t)hit_i * S.n_pos_lights + (lp0 + k)] = 0u;
+#pragma unroll 1
+        for (int k = 0; k < kPerThread; ++k) {
+            const uint32_t hit_i = first + (uint32_t)k * kBlock + threadIdx.x;
+            uint32_t keep = 0u;
+            if (hit_i < n_hits) {
+                const PhongHit h = load_phong_hit(S, Wk, Wk.phong_queue[hit_i]);
+                for (int q = 0; q < n; ++q) {
+                    const DLight& L = S.pos_lights[lp0 + q];
+                    const f3 comb = phong_term(L, h.m, h.mc, h.p, h.nrm, h.d);
+                    if (!(comb.x == 0.0f && comb.y == 0.0f && comb.z == 0.0f) && !surely_outside_cone(L, h.p)) keep |= 1u << q;
+                    Wk.vis[(size_t)hit_i * S.n_pos_lights + (lp0 + q)] = 0u;
+                }
             }
+            s_keep[k][threadIdx.x] = keep;
         }
-        uint32_t at[kAtOnce];
-        block_push_multi<kAtOnce>(Wk.light_count + lp0, n, keep, at);
+        uint32_t pred[kPerThread], at[kPerThread][kAtOnce];
 #pragma unroll
-        for (int k = 0; k < kAtOnce; ++k)
-            if (keep[k]) Wk.pair_seg[(size_t)(lp0 + k) * n_hits + at[k]] = hit_i;
+        for (int k = 0; k < kPerThread; ++k) pred[k] = s_keep[k][threadIdx.x];  // (a thread reads what it wrote itself)
+        uint32_t* counters[kAtOnce];
+#pragma unroll
+        for (int q = 0; q < kAtOnce; ++q) counters[q] = Wk.light_count + lp0 + (q < n ? q : 0);
+        block_push_qk<kAtOnce, kPerThread>(counters, n, pred, at);
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k)
+#pragma unroll
+            for (int q = 0; q < kAtOnce; ++q)
+                if ((pred[k] >> q) & 1u) Wk.pair_seg[(size_t)(lp0 + q) * n_hits + at[k][q]] = first + (uint32_t)k * kBlock + threadIdx.x;
     }
 }
 // exclusive prefix sums of the per-light pair counts; the total is the pair-queue length k_shadow reads
@@ -450,9 +524,14 @@ __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S,
     const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride, nullptr};
     uint32_t* const out_counter = Wk.light_count + 2 * S.n_pos_lights;
     unsigned long long decided = 0;
-    const uint32_t rounds = (n_pairs + gstride - 1) / gstride;  // the same for every thread: block_push is a block-wide operation
-    for (uint32_t it = 0; it < rounds; ++it) {
-        const uint32_t i = it * gstride + gtid;
+    const uint32_t rounds = (n_pairs + gstride - 1) / gstride;  // the same for every thread: block_push_qk is a block-wide operation
+    // kPerThread rounds, then ONE push per block for all of them (a pair's place in the queue is not needed before:
+    // its resume state is filed under (hit, light), not under that place)
+    for (uint32_t it0 = 0; it0 < rounds; it0 += kPerThread) {
+      uint32_t keep_bits = 0;
+#pragma unroll 1
+      for (uint32_t k = 0; k < (uint32_t)kPerThread && it0 + k < rounds; ++k) {
+        const uint32_t i = (it0 + k) * gstride + gtid;
         const bool live = i < n_pairs;
         uint32_t hl = 0, lp = 0, hit_i = 0;
         bool judge = false;
@@ -475,18 +554,31 @@ __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S,
             Wk.vis[(size_t)hit_i * S.n_pos_lights + lp] = (uint32_t)B.reps;
             decided += (unsigned long long)B.reps;
         }
-        const bool keep = live && !clear;
-        const uint32_t at = block_push(out_counter, keep);
-        if (keep) {
-            Wk.pair_seg[at] = hl;
+        if (live && !clear) {
+            keep_bits |= 1u << k;
             if (Wk.beam_state) {  // the walk's stack is still in place (LDS + spill region) until the next round
-                uint32_t* dst = Wk.beam_state + (size_t)at * kResumeWords;
+                uint32_t* dst = Wk.beam_state + ((size_t)hit_i * S.n_pos_lights + lp) * kResumeWords;
                 if (judge) write_resume(st, stop_block, stop_sp, dst); else dst[0] = kResumeRoot;
             }
         }
+      }
+      uint32_t pred[kPerThread], at[kPerThread][1];
+#pragma unroll
+      for (int k = 0; k < kPerThread; ++k) pred[k] = (keep_bits >> k) & 1u;
+      uint32_t* const counters[1] = {out_counter};
+      block_push_qk<1, kPerThread>(counters, 1, pred, at);
+#pragma unroll
+      for (int k = 0; k < kPerThread; ++k)
+          if (pred[k]) Wk.pair_seg[at[k][0]] = Wk.pairs[(it0 + (uint32_t)k) * gstride + gtid];
     }
     for (int off = 32; off > 0; off >>= 1) decided += __shfl_down(decided, off);
-    if (__lane_id() == 0 && decided) atomicAdd(Wk.frame_counters + 1, decided);
+    if (__lane_id() == 0 && decided) atomicAdd(Wk.frame_counters + 2 + kSubCounters + (blockIdx.x & (kSubCounters - 1)), decided);
+}
+// the call's two totals from the words the wavefronts added to (one wavefront)
+__global__ void k_sum_counters(unsigned long long* fc) {
+    unsigned long long a = fc[2 + threadIdx.x], b = fc[2 + kSubCounters + threadIdx.x];
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+    if (threadIdx.x == 0) { fc[0] = a; fc[1] = b; }
 }
 
 // One lane per (PhongBlinn hit, positional light, repetition lane).  group = lanes per (hit, light):
@@ -530,6 +622,7 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
             bool traced = false;
             f3 p = mk3(0.0f, 0.0f, 0.0f), dir = mk3(1.0f, 1.0f, 1.0f);
             float dist = 0.0f;
+            const uint32_t* resume = nullptr;  // what the pair's beam walk left (k_pair_beam), filed under (hit, light)
             if (active && rep < (uint32_t)B.reps) {
                 // everything about the ray is derived here, so nothing but the pair's index stays live
                 // across the traversal below.  The pair queue is light-major: the lane groups of a wavefront are
@@ -544,6 +637,7 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
                 const uint2 pk = Wk.path_key[slot];
                 const RngKey key{B.k0, B.k1, pk.x, pk.y};
                 const DLight& L = S.pos_lights[lp];
+                if (beam_state) resume = beam_state + ((size_t)hit_i * S.n_pos_lights + lp) * kResumeWords;
                 const f3 jit = scale3(0.25f, random_in_unit_sphere(key, (uint32_t)bounce, P_SHADOW, lp * (uint32_t)B.reps + rep));
                 const f3 shifted = add3(ld3(L.pos), jit);  // light.go:94 / :123
                 const f3 ld = sub3(shifted, p);  // doesReachLight, light.go:141-160
@@ -561,7 +655,7 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
 #ifdef RTGO_PROF
             // what fusing two consecutive rounds of a wavefront (a lane going on to its second ray as soon as its first is done) could give
             uint32_t pv = 0, pit = 0;
-            const bool occ = occluded<true>(S, st, traced, p, dir, 0.01f, dist, beam_state ? beam_state + (size_t)pi * kResumeWords : nullptr, &pv, &pit);
+            const bool occ = occluded<true>(S, st, traced, p, dir, 0.01f, dist, resume, &pv, &pit);
             if (it & 1u) {
                 uint32_t both = pv + prof_prev_visits, sum = both, mx = both;
                 for (int off = 32; off > 0; off >>= 1) { sum += __shfl_xor(sum, off); const uint32_t o2 = __shfl_xor(mx, off); mx = mx > o2 ? mx : o2; }
@@ -575,7 +669,7 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
             }
             prof_prev_visits = pv; prof_prev_iters = pit;
 #else
-            const bool occ = occluded<true>(S, st, traced, p, dir, 0.01f, dist, beam_state ? beam_state + (size_t)pi * kResumeWords : nullptr);
+            const bool occ = occluded<true>(S, st, traced, p, dir, 0.01f, dist, resume);
 #endif
             // the visible repetitions of a (hit, light) counted over its lane group: an integer, no summation order
             const unsigned long long m = __ballot(traced && !occ);
@@ -594,7 +688,7 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
         }
     }
     // shadow rays actually traced: one 64-bit atomic per wavefront
-    if (lane == 0 && launched) atomicAdd(Wk.frame_counters, launched);
+    if (lane == 0 && launched) atomicAdd(Wk.frame_counters + 2 + (blockIdx.x & (kSubCounters - 1)), launched);
 }
 
 
@@ -913,7 +1007,7 @@ size_t carve_work(Work* w, unsigned char* base, int64_t paths, int depth, int lp
     w->pair_seg = (uint32_t*)take(P * L * sizeof(uint32_t));
     w->light_count = (uint32_t*)take((2 * L + 2) * sizeof(uint32_t));
     w->counters = (uint32_t*)take((size_t)(3 * depth + 8) * sizeof(uint32_t));
-    w->frame_counters = (unsigned long long*)take(4 * sizeof(unsigned long long));
+    w->frame_counters = (unsigned long long*)take((2 + 2 * kSubCounters) * sizeof(unsigned long long));
     w->overflow = (uint32_t*)take((size_t)overflow_entries * sizeof(uint32_t));
     w->beam_state = nullptr;  // a buffer of its own (Lane::beam_state), made by the calls that walk pair beams
     return off;
@@ -1574,7 +1668,7 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
     struct Span { int a, b; int kind; };  // kind 0 = k_extend, 1 = k_shadow
     std::vector<Span> spans;
     if (timed) HIP_TRY(hipEventRecord(ln.ev_frame[0], stream));
-    HIP_TRY(hipMemsetAsync(wk.frame_counters, 0, 4 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(wk.frame_counters, 0, (2 + 2 * kSubCounters) * sizeof(unsigned long long), stream));
     const DCamera cam = make_camera(s, W, H);
     for (int s0 = P.sA; s0 < P.sB; s0 += P.ns_max) {
         const int ns = std::min(P.ns_max, P.sB - s0);
@@ -1588,7 +1682,7 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
             B.k0 = (uint32_t)P.part.seed; B.k1 = (uint32_t)(P.part.seed >> 32);
             const long long slots = (long long)B.npix * ns;
             HIP_TRY(hipMemsetAsync(wk.counters, 0, n_ctr * sizeof(uint32_t), stream));
-            hipLaunchKernelGGL(k_raygen, dim3((unsigned)((slots + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, B, cam, wk);
+            hipLaunchKernelGGL(k_raygen, dim3((unsigned)((slots + kBlock * kPerThread - 1) / (kBlock * kPerThread))), dim3(kBlock), 0, stream, B, cam, wk);
             uint32_t bound = (uint32_t)slots;  // >= the length of the queue of bounce b
             for (int b = 0; b < D && bound > 0; ++b) {
                 uint32_t* q = wk.queue[b & 1];
@@ -1599,7 +1693,7 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
                 if (staged) se.a = stamp();
                 hipLaunchKernelGGL(k_extend, dim3(grid_for(bound, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, wk, q, n_rays);
                 if (staged) se.b = stamp();
-                hipLaunchKernelGGL(k_shade, dim3((bound + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, B, wk, q, n_rays, qn, b);
+                hipLaunchKernelGGL(k_shade, dim3((bound + kBlock * kPerThread - 1) / (kBlock * kPerThread)), dim3(kBlock), 0, stream, s->d, B, wk, q, n_rays, qn, b);
                 uint32_t* snap = ln.h_counters + (size_t)(b & 1) * ln.h_counter_words;
                 HIP_TRY(hipMemcpyAsync(snap, wk.counters, n_ctr * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipEventRecord(ln.ev_snap[b & 1], stream));
@@ -1608,7 +1702,7 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
                     const unsigned long long n_pairs = (unsigned long long)bound * L;
                     uint32_t* pair_counter = wk.counters + 2 * D + 4 + b;
                     HIP_TRY(hipMemsetAsync(wk.light_count, 0, (size_t)L * sizeof(uint32_t), stream));
-                    hipLaunchKernelGGL(k_phong_pairs, dim3((bound + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, s->d, wk, n_phong);
+                    hipLaunchKernelGGL(k_phong_pairs, dim3((bound + kBlock * kPerThread - 1) / (kBlock * kPerThread)), dim3(kBlock), 0, stream, s->d, wk, n_phong);
                     hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(64), 0, stream, wk, L, pair_counter);
                     hipLaunchKernelGGL(k_pair_compact, dim3((bound + kBlock - 1) / kBlock, (unsigned)std::min(L, 65535)), dim3(kBlock), 0, stream, wk, n_phong, L);
                     if (reps > 0) {
@@ -1647,6 +1741,7 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
     HIP_TRY(hipGetLastError());
     if (stats) {
         unsigned long long* fc = reinterpret_cast<unsigned long long*>(ln.h_counters + 2 * ln.h_counter_words);
+        hipLaunchKernelGGL(k_sum_counters, dim3(1), dim3(kSubCounters), 0, stream, wk.frame_counters);
         HIP_TRY(hipMemcpyAsync(fc, wk.frame_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipEventRecord(ln.ev_frame[1], stream));
         HIP_TRY(hipEventSynchronize(ln.ev_frame[1]));
