@@ -543,7 +543,7 @@ RT_DEV void queue_qleaves(uint32_t* pend, uint32_t stride, const uint4& h1, uint
     }
     *npend = n;
 }
-// Hit inner children in RAY order: the nearest is entered, the others pushed far to near.  A child's block is the
+// Hit inner children: the first is entered, the others pushed last to first.  A child's block is the
 // block's first child block + its rank among the inner children (slot order).
 #ifdef RTGO_PUSH_BRANCHFREE
 RT_DEV bool next_qblock(const TraceStack& st, const uint4& h1, uint32_t, uint32_t inner_hits, uint32_t sign, uint32_t* cur, int* sp_io) {
@@ -578,13 +578,22 @@ RT_DEV bool next_qblock(const TraceStack& st, const uint4& h1, uint32_t, uint32_
 RT_DEV bool next_qblock(const TraceStack& st, const uint4& h1, uint32_t present, uint32_t inner_hits, uint32_t sign, uint32_t* cur, int* sp_io) {
     int sp = *sp_io;
     if (inner_hits) {
+        // in SLOT order, whatever the ray's direction: the answer is an OR over the subtrees, and bringing the mask into
+        // ray order (16 instructions per visit, + 1 per child for its slot) bought these walks nothing — config 3,
+        // k_shadow alone: 256.1 ms in octant order, 256.5 with the whole order reversed for rays that go down two or
+        // three axes, 252.0 like this
+#ifdef RTGO_RAY_ORDER
         uint32_t m = ray_order8(inner_hits, sign);
+#else
+        uint32_t m = inner_hits;
+        sign = 0u;
+#endif
         const uint32_t base = h1.x & 0xffffffu;
         const uint32_t inner = present & ~(h1.x >> 24);  // the slots that hold inner children
-        const int kn = __ffs((int)m) - 1;             // nearest: lowest ray-order position
+        const int kn = __ffs((int)m) - 1;             // entered now: the lowest position
         m &= m - 1u;
         while (m) {
-            const int k = 31 - __clz((int)m);          // farthest first
+            const int k = 31 - __clz((int)m);          // highest first
             m ^= 1u << k;
             const uint32_t slot = (uint32_t)k ^ sign;
             st.put(sp++, base + (uint32_t)__popc(inner & ((1u << slot) - 1u)));
