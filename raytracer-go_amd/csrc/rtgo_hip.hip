@@ -515,6 +515,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_compact(Work Wk, const uint32_t
 #ifndef RTGO_BEAM_WAVES
 #define RTGO_BEAM_WAVES 7  // frame ms at config 3: 5 waves (86 VGPRs, the compiler's own choice) 308-310, 6 (78) 307.5, 7 (72) 303.5-304.2; the block's 20.5 KB of LDS allow no 8th
 #endif
+constexpr float kBeamR = 0.25f * 1.0001f + 1e-5f;  // half-width of the cube that holds every jittered light position (light.go:94), with margin
 __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S, Batch B, Work Wk, const uint32_t* n_hits_ptr, const uint32_t* pair_counter) {
     __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
     (void)n_hits_ptr;
@@ -545,11 +546,19 @@ __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S,
             const f3 p = add3(mk3(ro.x, ro.y, ro.z), scale3(ro.w, mk3(rdv.x, rdv.y, rdv.z)));
             const DLight& L = S.pos_lights[lp];
             judge = surely_inside_cone(L, p);
-            if (judge) bm = make_beam(p, ld3(L.pos), 0.25f * 1.0001f + 1e-5f, 0.01f);
+            if (judge) bm = make_beam(p, ld3(L.pos), kBeamR, 0.01f);
         }
         uint32_t stop_block = 0;
         int stop_sp = 0;
-        const bool clear = beam_is_clear(S, st, judge, bm, &stop_block, &stop_sp) && judge;
+        // (the pair's point and light once more, for the few leaves whose box the beam meets: not kept across the walk)
+        const auto origin = [&](f3* p_out, f3* D_out) {
+            const uint32_t slot = Wk.phong_queue[hit_i];
+            const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
+            const f3 p = add3(mk3(ro.x, ro.y, ro.z), scale3(ro.w, mk3(rdv.x, rdv.y, rdv.z)));
+            *p_out = p;
+            *D_out = sub3(ld3(S.pos_lights[lp].pos), p);
+        };
+        const bool clear = beam_is_clear(S, st, judge, bm, kBeamR, origin, &stop_block, &stop_sp) && judge;
         if (clear) {
             Wk.vis[(size_t)hit_i * S.n_pos_lights + lp] = (uint32_t)B.reps;
             decided += (unsigned long long)B.reps;
@@ -579,6 +588,52 @@ __global__ void k_sum_counters(unsigned long long* fc) {
     unsigned long long a = fc[2 + threadIdx.x], b = fc[2 + kSubCounters + threadIdx.x];
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
     if (threadIdx.x == 0) { fc[0] = a; fc[1] = b; }
+}
+
+// Scene set-up: one thread per child record; a leaf's record files the leaf's exact box and its slab under the leaf's
+// first shape (DScene::leaf_bound, device_math.hpp "leaf slabs").  n = the mean of the leaf's triangle normals (each
+// turned to the side of the first), narrowed to float32; dmin / dmax = the range of n . (vertex - box.min) over the
+// leaf's vertices in float64 with that float32 n, widened by 2^-16 of the box's size and rounded outward.  A leaf
+// with a sphere, or whose normals cancel, gets n = 0 and [-inf, +inf]: it is never culled.
+__global__ __launch_bounds__(kBlock) void k_leaf_bounds(const float4* recs, const float4* prims, uint32_t n_recs, float4* leaf_bound) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_recs) return;
+    const float4 a = recs[2 * (size_t)i], b = recs[2 * (size_t)i + 1];
+    const uint32_t w0 = __float_as_uint(b.z), w1 = __float_as_uint(b.w);
+    if (!(w1 & kLeafFlag)) return;
+    const uint32_t first = w0 >> 8, count = w0 & 0xffu;
+    double ns[3] = {0.0, 0.0, 0.0};
+    bool flat = true;
+    for (uint32_t k = 0; k < count; ++k) {
+        const float4 p0 = prims[3 * (size_t)(first + k)], p1 = prims[3 * (size_t)(first + k) + 1], p2 = prims[3 * (size_t)(first + k) + 2];
+        if (!(__float_as_uint(p2.y) & kPrimTriangle)) { flat = false; break; }
+        const double e1[3] = {(double)p0.w - p0.x, (double)p1.x - p0.y, (double)p1.y - p0.z}, e2[3] = {(double)p1.z - p0.x, (double)p1.w - p0.y, (double)p2.x - p0.z};
+        double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        if (n[0] * ns[0] + n[1] * ns[1] + n[2] * ns[2] < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+        ns[0] += n[0]; ns[1] += n[1]; ns[2] += n[2];
+    }
+    const double len = sqrt(ns[0] * ns[0] + ns[1] * ns[1] + ns[2] * ns[2]);
+    float nf[3] = {0.0f, 0.0f, 0.0f};
+    float dmin = -__builtin_inff(), dmax = __builtin_inff();
+    if (flat && len > 0.0 && len < 1e300) {
+        for (int k = 0; k < 3; ++k) nf[k] = (float)(ns[k] / len);
+        double lo = 1e300, hi = -1e300;
+        for (uint32_t k = 0; k < count; ++k) {
+            const float4 p0 = prims[3 * (size_t)(first + k)], p1 = prims[3 * (size_t)(first + k) + 1], p2 = prims[3 * (size_t)(first + k) + 2];
+            const double v[3][3] = {{p0.x, p0.y, p0.z}, {p0.w, p1.x, p1.y}, {p1.z, p1.w, p2.x}};
+            for (int q = 0; q < 3; ++q) {
+                const double t = ((double)nf[0] * (v[q][0] - (double)a.x) + (double)nf[1] * (v[q][1] - (double)a.y)) + (double)nf[2] * (v[q][2] - (double)a.z);
+                lo = t < lo ? t : lo; hi = t > hi ? t : hi;
+            }
+        }
+        const double pad = 1.52587890625e-05 * ((((double)a.w - a.x) + ((double)b.x - a.y)) + ((double)b.y - a.z)) + 1e-30;
+        dmin = __double2float_rd(lo - pad);
+        dmax = __double2float_ru(hi + pad);
+    }
+    float4* out = leaf_bound + 3 * (size_t)first;
+    out[0] = a;
+    out[1] = make_float4(b.x, b.y, nf[0], nf[1]);
+    out[2] = make_float4(nf[2], dmin, dmax, 0.0f);
 }
 
 // One lane per (PhongBlinn hit, positional light, repetition lane).  group = lanes per (hit, light):
@@ -955,7 +1010,7 @@ constexpr int kLanes = 4;
 struct rt_scene {
     int device = 0;
     DScene d{};
-    void* d_recs = nullptr; void* d_qblocks = nullptr; void* d_prims = nullptr; void* d_tprims = nullptr; void* d_prim_ids = nullptr; void* d_block_first = nullptr; void* d_block_box = nullptr; void* d_mats = nullptr; void* d_texs = nullptr; void* d_lights = nullptr;
+    void* d_recs = nullptr; void* d_qblocks = nullptr; void* d_prims = nullptr; void* d_tprims = nullptr; void* d_prim_ids = nullptr; void* d_block_first = nullptr; void* d_block_box = nullptr; void* d_leaf_bound = nullptr; void* d_mats = nullptr; void* d_texs = nullptr; void* d_lights = nullptr;
     std::vector<void*> d_tex_pixels;
     rt_scene_info info{};
     double ms_build = 0;
@@ -1441,6 +1496,19 @@ static int finish_scene(const rt_scene_desc* desc, const HostScene& h, rt_scene*
     HIP_TRY_S(hipMemcpy(s->d_block_first, h.flat.block_first.data(), h.flat.block_first.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_block_box, h.flat.block_box.size() * sizeof(float)));
     HIP_TRY_S(hipMemcpy(s->d_block_box, h.flat.block_box.data(), h.flat.block_box.size() * sizeof(float), hipMemcpyHostToDevice));
+    // the leaves' slabs, filed under each leaf's first shape: made on the device from the records and shapes just uploaded
+    // (RTGO_SLAB=0: none, an A/B switch).  Unfiled entries are never read; the kernel runs on the null stream, before any render.
+    const char* slab_env = std::getenv("RTGO_SLAB");
+    const bool slabs = RTGO_LEAF_SLAB && !(slab_env && std::strcmp(slab_env, "0") == 0) && !h.flat.records.empty();
+    const size_t leaf_bound_bytes = slabs ? h.prim_words * sizeof(float) : 0;
+    if (slabs) {
+        HIP_TRY_S(hipMalloc(&s->d_leaf_bound, leaf_bound_bytes));
+        const uint32_t n_recs = (uint32_t)h.flat.records.size();
+        hipLaunchKernelGGL(k_leaf_bounds, dim3((n_recs + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, (const float4*)s->d_recs, (const float4*)s->d_prims, n_recs,
+                           (float4*)s->d_leaf_bound);
+        HIP_TRY_S(hipGetLastError());
+        HIP_TRY_S(hipDeviceSynchronize());
+    }
     HIP_TRY_S(hipMalloc(&s->d_mats, h.mats.size() * sizeof(DMaterial)));
     HIP_TRY_S(hipMemcpy(s->d_mats, h.mats.data(), h.mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
     HIP_TRY_S(hipMalloc(&s->d_texs, texs.size() * sizeof(DTexture)));
@@ -1453,7 +1521,7 @@ static int finish_scene(const rt_scene_desc* desc, const HostScene& h, rt_scene*
     const int spill = h.flat.stack_bound + 1 > kLdsStackDepth ? h.flat.stack_bound + 1 - kLdsStackDepth : 0;  // +1: the nearest child is pushed, then popped
     s->spill = spill;  // the region itself is sized by ensure_overflow() for the grids a call really launches
 
-    s->d.recs = (const float4*)s->d_recs; s->d.qblocks = (const uint4*)s->d_qblocks; s->d.prims = (const float4*)s->d_prims; s->d.tprims = (const float4*)s->d_tprims; s->d.prim_ids = (const int*)s->d_prim_ids; s->d.block_first = (const uint32_t*)s->d_block_first; s->d.block_box = (const float4*)s->d_block_box;
+    s->d.recs = (const float4*)s->d_recs; s->d.qblocks = (const uint4*)s->d_qblocks; s->d.prims = (const float4*)s->d_prims; s->d.tprims = (const float4*)s->d_tprims; s->d.prim_ids = (const int*)s->d_prim_ids; s->d.block_first = (const uint32_t*)s->d_block_first; s->d.block_box = (const float4*)s->d_block_box; s->d.leaf_bound = (const float4*)s->d_leaf_bound;
     s->d.materials = (const DMaterial*)s->d_mats; s->d.textures = (const DTexture*)s->d_texs;
     s->d.lights = (const DLight*)s->d_lights;
     s->d.pos_lights = s->d.lights + desc->n_lights + 1;
@@ -1466,7 +1534,7 @@ static int finish_scene(const rt_scene_desc* desc, const HostScene& h, rt_scene*
     s->info.n_shapes = desc->n_shapes; s->info.n_inner_nodes = h.flat.n_inner;
     s->info.n_child_records = (int64_t)h.flat.records.size();
     s->info.tree_depth = h.flat.depth; s->info.stack_bound = h.flat.stack_bound;
-    s->info.device_bytes = (int64_t)(rec_bytes + h.flat.qblocks.size() * 4 + h.prim_words * 4 + h.prim_words * 4 + h.mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
+    s->info.device_bytes = (int64_t)(rec_bytes + h.flat.qblocks.size() * 4 + h.prim_words * 4 + h.prim_words * 4 + leaf_bound_bytes + h.mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
                                      h.lights.size() * sizeof(DLight)) + tex_bytes;  // + the spill region, see ensure_overflow()
     lap("events");
     return RT_OK;
@@ -1517,7 +1585,7 @@ void rt_scene_destroy(rt_scene* s) {
     }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     for (auto& e : s->ev_wall) if (e) (void)hipEventDestroy(e);
-    void* ptrs[] = {s->d_recs, s->d_qblocks, s->d_prims, s->d_tprims, s->d_prim_ids, s->d_block_first, s->d_block_box, s->d_mats, s->d_texs, s->d_lights};
+    void* ptrs[] = {s->d_recs, s->d_qblocks, s->d_prims, s->d_tprims, s->d_prim_ids, s->d_block_first, s->d_block_box, s->d_leaf_bound, s->d_mats, s->d_texs, s->d_lights};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : s->d_tex_pixels) (void)hipFree(p);
     for (DevBuf* b : {&s->accum, &s->rgba, &s->probe_in, &s->probe_out, &s->probe_out2}) b->release();

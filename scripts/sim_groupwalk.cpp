@@ -982,3 +982,290 @@ extern "C" int sim_beam_k(const orc_scene* s, const rt_image_spec* spec, uint64_
         }
     return 0;
 }
+
+// ---- leaf slabs: a second bound per leaf, two parallel planes around its shapes ---------------------------------
+// A leaf's axis-aligned box is loose around a tilted patch of surface; a shadow ray that meets the box but not the patch
+// pays for every shape of the leaf.  Here every leaf also gets a slab {x : dmin <= n . x <= dmax}; a ray tests its
+// shapes only if, inside the box's [tn, tf], it also crosses the slab.  mode 0: n = the leaf's mean triangle normal;
+// mode 1: n = the best of 10 fixed diagonals (4 body, 6 face).  out (occluded rays / others): [0]/[6] rays,
+// [1]/[7] block visits, [2]/[8] leaf boxes met, [3]/[9] of which the slab is met too, [4]/[10] shape tests without the
+// slab, [5]/[11] shape tests with it; [12] rays whose answer the slab changed (must be 0).
+extern "C" int sim_leaf_slab(const orc_scene* s, const rt_image_spec* spec, uint64_t seed, int mode, double* out) {
+    const Scene& sc = s->sc;
+    const int W = spec->width, H = spec->height, reps = spec->soft_shadow_monte_carlo_repetitions;
+    const CameraF64 c64 = new_camera(sc, W, H);
+    const Camera<float> cf = narrow_camera<float>(c64);
+    const Tables<float>& T = sc.t32;
+    Node* root = effective(sc.wide_root);
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    if (root->as_leaf) return 0;
+    struct Slab { double n[3], dmin, dmax; bool any; };
+    std::unordered_map<Node*, Slab> slabs;
+    static const double dirs[10][3] = {{1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}, {1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1}};
+    auto slab_of = [&](Node* lf) -> const Slab& {
+        auto it = slabs.find(lf);
+        if (it != slabs.end()) return it->second;
+        Slab sl{};
+        sl.any = true;
+        std::vector<int> g;
+        subtree_shapes(lf, &g);
+        std::vector<std::array<double, 3>> pts;
+        double nsum[3] = {0, 0, 0};
+        for (int shape : g) {
+            const Shape<float>& sh = T.shapes[(size_t)shape];
+            if (sh.kind != RT_SHAPE_TRIANGLE) { sl.any = false; break; }
+            const double a[3] = {sh.a.x, sh.a.y, sh.a.z}, b[3] = {sh.b.x, sh.b.y, sh.b.z}, c[3] = {sh.c.x, sh.c.y, sh.c.z};
+            const double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+            double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            if (n[0] * nsum[0] + n[1] * nsum[1] + n[2] * nsum[2] < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+            for (int k = 0; k < 3; ++k) nsum[k] += n[k];
+            pts.push_back({a[0], a[1], a[2]}); pts.push_back({b[0], b[1], b[2]}); pts.push_back({c[0], c[1], c[2]});
+        }
+        if (sl.any) {
+            auto span = [&](const double* n, double* lo, double* hi) {
+                *lo = 1e300; *hi = -1e300;
+                for (auto& p : pts) { const double v = n[0] * p[0] + n[1] * p[1] + n[2] * p[2]; *lo = std::min(*lo, v); *hi = std::max(*hi, v); }
+            };
+            if (mode == 0) {
+                const double len = std::sqrt(nsum[0] * nsum[0] + nsum[1] * nsum[1] + nsum[2] * nsum[2]);
+                if (len > 0) { for (int k = 0; k < 3; ++k) sl.n[k] = nsum[k] / len; span(sl.n, &sl.dmin, &sl.dmax); } else sl.any = false;
+            } else {
+                double best = 1e300;
+                for (auto& d : dirs) {
+                    const double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                    double lo, hi; span(d, &lo, &hi);
+                    if ((hi - lo) / len < best) { best = (hi - lo) / len; for (int k = 0; k < 3; ++k) sl.n[k] = d[k]; sl.dmin = lo; sl.dmax = hi; }
+                }
+            }
+            const double pad = 1e-5 * (std::fabs(sl.dmin) + std::fabs(sl.dmax) + 1e-3);
+            sl.dmin -= pad; sl.dmax += pad;
+        }
+        return slabs.emplace(lf, sl).first->second;
+    };
+    // returns 0 = unoccluded, 1 = occluded; counts into c[0..4] = visits, leaf boxes, slabs passed, shapes plain, shapes with slab
+    auto walk = [&](const Ray<float>& r, float tmin, float tmax, double* c, bool use_slab) {
+        const StackRay sr = make_stack_ray(r);
+        std::vector<Node*> stack;
+        std::vector<int> group;
+        Node* cur = root;
+        for (;;) {
+            c[0] += 1;
+            Node* pending[8]; int np = 0;
+            for (int k = 0; k < 8; ++k) {
+                Node* e = cur->slot[k ^ sr.sign];
+                if (!e) continue;
+                float tn = tmin, tf = tmax;
+                for (int a = 0; a < 3; ++a) {
+                    const float lo = (sr.sign >> a) & 1 ? e->fmax[a] : e->fmin[a], hi = (sr.sign >> a) & 1 ? e->fmin[a] : e->fmax[a];
+                    const float t0 = lo * sr.inv[a] - sr.oi[a], t1 = hi * sr.inv[a] - sr.oi[a];
+                    if (t0 == t0) tn = std::max(tn, t0);
+                    if (t1 == t1) tf = std::min(tf, t1);
+                }
+                if (!(tn <= tf)) continue;
+                if (e->as_leaf) {
+                    c[1] += 1;
+                    if (use_slab) {
+                        const Slab& sl = slab_of(e);
+                        if (sl.any) {
+                            const double so = sl.n[0] * r.p.x + sl.n[1] * r.p.y + sl.n[2] * r.p.z, sd = sl.n[0] * r.d.x + sl.n[1] * r.d.y + sl.n[2] * r.d.z;
+                            const double a0 = so + (double)tn * sd, a1 = so + (double)tf * sd;
+                            const double m = 1e-5 * (std::fabs(a0) + std::fabs(a1));
+                            if (std::max(a0, a1) + m < sl.dmin || std::min(a0, a1) - m > sl.dmax) continue;
+                        }
+                    }
+                    c[2] += 1;
+                    group.clear();
+                    subtree_shapes(e, &group);
+                    for (int shape : group) {
+                        c[3] += 1;
+                        const Hit<float> sh = T.shapes[(size_t)shape].kind == RT_SHAPE_TRIANGLE ? triangle_occludes_f32(T.shapes[(size_t)shape], shape, r, tmin, tmax)
+                                                                                                : shape_hit(T, shape, r, tmin, tmax);
+                        if (sh.t > 0.0f && sh.t <= tmax) return true;
+                    }
+                    continue;
+                }
+                pending[np++] = e;
+            }
+            for (int i = np - 1; i >= 1; --i) stack.push_back(pending[i]);
+            if (np > 0) { cur = pending[0]; continue; }
+            if (stack.empty()) return false;
+            cur = stack.back();
+            stack.pop_back();
+        }
+    };
+    for (int row = 0; row < H; ++row)
+        for (int i = 0; i < W; ++i) {
+            const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(row * W + i), 0u};
+            const Ray<float> r = camera_ray(cf, W, H, i, H - 1 - row, key);
+            Hit<float> hit;
+            if (!trace_stack_f32(sc, r, 0.0f, FLT_MAX, false, hit, nullptr)) continue;
+            const Shape<float>& sh = T.shapes[hit.shape];
+            const Material<float>& m = T.materials[sh.material];
+            if (m.kind != RT_MAT_PHONGBLINN) continue;
+            int lpos = -1;
+            for (size_t li = 0; li < T.lights.size(); ++li) {
+                const Light<float>& L = T.lights[li];
+                if (L.kind == RT_LIGHT_AMBIENT) continue;
+                ++lpos;
+                const V3<float> ldir = unit(sub(L.pos, hit.p));
+                const float inten = saturate(dot(hit.normal, ldir));
+                const V3<float> h = unit(add(ldir, r.d));
+                const float si = std::pow(saturate(dot(hit.normal, h)), m.param);
+                if (inten == 0.0f && (si == 0.0f || (m.spec.x == 0 && m.spec.y == 0 && m.spec.z == 0))) continue;
+                for (int k = 0; k < reps; ++k) {
+                    const V3<float> jit = scale(0.25f, random_in_unit_sphere<float>(key, 0, P_SHADOW, (uint32_t)(lpos * reps + k)));
+                    const V3<float> shifted = add(L.pos, jit);
+                    if (L.kind == RT_LIGHT_SPOT && !(dot(L.look_dir, unit(sub(hit.p, shifted))) >= L.cos_angle)) continue;
+                    const V3<float> ld = sub(shifted, hit.p);
+                    const float d = norm(ld);
+                    const Ray<float> sray{hit.p, scale(1.0f / d, ld)};
+                    double c0[5] = {0, 0, 0, 0, 0}, c1[5] = {0, 0, 0, 0, 0};
+                    const bool oc = walk(sray, 0.01f, d, c0, false);
+                    const bool oc1 = walk(sray, 0.01f, d, c1, true);
+                    if (oc != oc1) out[12] += 1;
+                    double* o = oc ? out : out + 6;
+                    o[0] += 1; o[1] += c1[0]; o[2] += c1[1]; o[3] += c1[2]; o[4] += c0[3]; o[5] += c1[3];
+                }
+            }
+        }
+    return 0;
+}
+
+// ---- pair beams with leaf slabs: a beam that meets a leaf's box must also meet the leaf's slab (sim_leaf_slab, mean
+// normal) to count as meeting the leaf.  out: [0] pairs, [1] rays, [2] pairs clear by boxes alone, [3] their rays,
+// [4] pairs clear with slabs, [5] their rays, [6] clear pairs (with slabs) holding an occluded ray (must be 0),
+// [7] beam visits without slabs, [8] beam visits with slabs (walks go on past leaves whose slab is missed),
+// [9] leaf boxes met by beams in the slab walk, [10] rays of pairs that are not clear with slabs but whose rays are all unoccluded,
+// [11] rays of pairs with all rays occluded, [12] occluded rays
+extern "C" int sim_ball_beam_slab(const orc_scene* s, const rt_image_spec* spec, uint64_t seed, double R, double* out) {
+    const Scene& sc = s->sc;
+    const int W = spec->width, H = spec->height, reps = spec->soft_shadow_monte_carlo_repetitions;
+    const CameraF64 c64 = new_camera(sc, W, H);
+    const Camera<float> cf = narrow_camera<float>(c64);
+    const Tables<float>& T = sc.t32;
+    Node* root = effective(sc.wide_root);
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    if (root->as_leaf) return 0;
+    struct Slab { double n[3], dmin, dmax; bool any; };
+    std::unordered_map<Node*, Slab> slabs;
+    auto slab_of = [&](Node* lf) -> const Slab& {
+        auto it = slabs.find(lf);
+        if (it != slabs.end()) return it->second;
+        Slab sl{};
+        sl.any = true;
+        std::vector<int> g;
+        subtree_shapes(lf, &g);
+        std::vector<std::array<double, 3>> pts;
+        double nsum[3] = {0, 0, 0};
+        for (int shape : g) {
+            const Shape<float>& sh = T.shapes[(size_t)shape];
+            if (sh.kind != RT_SHAPE_TRIANGLE) { sl.any = false; break; }
+            const double a[3] = {sh.a.x, sh.a.y, sh.a.z}, b[3] = {sh.b.x, sh.b.y, sh.b.z}, c[3] = {sh.c.x, sh.c.y, sh.c.z};
+            const double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+            double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            if (n[0] * nsum[0] + n[1] * nsum[1] + n[2] * nsum[2] < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+            for (int k = 0; k < 3; ++k) nsum[k] += n[k];
+            pts.push_back({a[0], a[1], a[2]}); pts.push_back({b[0], b[1], b[2]}); pts.push_back({c[0], c[1], c[2]});
+        }
+        if (sl.any) {
+            const double len = std::sqrt(nsum[0] * nsum[0] + nsum[1] * nsum[1] + nsum[2] * nsum[2]);
+            if (len > 0) {
+                for (int k = 0; k < 3; ++k) sl.n[k] = nsum[k] / len;
+                sl.dmin = 1e300; sl.dmax = -1e300;
+                for (auto& p : pts) { const double v = sl.n[0] * p[0] + sl.n[1] * p[1] + sl.n[2] * p[2]; sl.dmin = std::min(sl.dmin, v); sl.dmax = std::max(sl.dmax, v); }
+                const double pad = 1e-5 * (std::fabs(sl.dmin) + std::fabs(sl.dmax) + 1e-3);
+                sl.dmin -= pad; sl.dmax += pad;
+            } else sl.any = false;
+        }
+        return slabs.emplace(lf, sl).first->second;
+    };
+    for (int row = 0; row < H; ++row)
+        for (int i = 0; i < W; ++i) {
+            const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(row * W + i), 0u};
+            const Ray<float> r = camera_ray(cf, W, H, i, H - 1 - row, key);
+            Hit<float> hit;
+            if (!trace_stack_f32(sc, r, 0.0f, FLT_MAX, false, hit, nullptr)) continue;
+            const Shape<float>& sh = T.shapes[hit.shape];
+            const Material<float>& m = T.materials[sh.material];
+            if (m.kind != RT_MAT_PHONGBLINN) continue;
+            int lpos = -1;
+            for (size_t li = 0; li < T.lights.size(); ++li) {
+                const Light<float>& L = T.lights[li];
+                if (L.kind == RT_LIGHT_AMBIENT) continue;
+                ++lpos;
+                const V3<float> ldir = unit(sub(L.pos, hit.p));
+                const float inten = saturate(dot(hit.normal, ldir));
+                const V3<float> h = unit(add(ldir, r.d));
+                const float si = std::pow(saturate(dot(hit.normal, h)), m.param);
+                if (inten == 0.0f && (si == 0.0f || (m.spec.x == 0 && m.spec.y == 0 && m.spec.z == 0))) continue;
+                int n_rays = 0, n_occ = 0;
+                for (int k = 0; k < reps; ++k) {
+                    const V3<float> jit = scale(0.25f, random_in_unit_sphere<float>(key, 0, P_SHADOW, (uint32_t)(lpos * reps + k)));
+                    const V3<float> shifted = add(L.pos, jit);
+                    if (L.kind == RT_LIGHT_SPOT && !(dot(L.look_dir, unit(sub(hit.p, shifted))) >= L.cos_angle)) continue;
+                    const V3<float> ld = sub(shifted, hit.p);
+                    const float d = norm(ld);
+                    Hit<float> hh;
+                    const bool oc = trace_stack_f32(sc, Ray<float>{hit.p, scale(1.0f / d, ld)}, 0.01f, d, true, hh, nullptr);
+                    n_occ += oc ? 1 : 0;
+                    ++n_rays;
+                }
+                if (n_rays == 0) continue;
+                const double p[3] = {hit.p.x, hit.p.y, hit.p.z};
+                const double D[3] = {L.pos.x - p[0], L.pos.y - p[1], L.pos.z - p[2]};
+                const double len = std::sqrt(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);
+                const double s0 = 0.01 / (len + R * 1.7320508) * 0.999, s1 = 1.0001;
+                const int sign = (D[0] < 0 ? 1 : 0) | (D[1] < 0 ? 2 : 0) | (D[2] < 0 ? 4 : 0);
+                auto meets = [&](const float* lo, const float* hi, double* a_out, double* b_out) {
+                    double a = s0, b = s1;
+                    for (int ax = 0; ax < 3; ++ax) {
+                        const double c1 = D[ax] - R, c2 = D[ax] + R;
+                        const double h1 = (double)hi[ax] - p[ax], l1 = (double)lo[ax] - p[ax];
+                        if (c1 > 0) b = std::min(b, h1 / c1); else if (c1 < 0) a = std::max(a, h1 / c1); else if (h1 < 0) return false;
+                        if (c2 > 0) a = std::max(a, l1 / c2); else if (c2 < 0) b = std::min(b, l1 / c2); else if (l1 > 0) return false;
+                    }
+                    *a_out = a; *b_out = b;
+                    return a <= b;
+                };
+                for (int pass = 0; pass < 2; ++pass) {
+                    double visits = 0; bool clear = true;
+                    std::vector<Node*> stack;
+                    Node* cur = root;
+                    while (cur && clear) {
+                        visits += 1;
+                        Node* pending[8]; int np = 0;
+                        for (int k = 0; k < 8 && clear; ++k) {
+                            Node* e = cur->slot[k ^ sign];
+                            double a, b;
+                            if (!e || !meets(e->fmin, e->fmax, &a, &b)) continue;
+                            if (e->as_leaf) {
+                                if (pass == 0) { clear = false; continue; }
+                                out[9] += 1;
+                                const Slab& sl = slab_of(e);
+                                if (!sl.any) { clear = false; continue; }
+                                const double np_ = sl.n[0] * p[0] + sl.n[1] * p[1] + sl.n[2] * p[2], nD = sl.n[0] * D[0] + sl.n[1] * D[1] + sl.n[2] * D[2];
+                                const double n1 = R * (std::fabs(sl.n[0]) + std::fabs(sl.n[1]) + std::fabs(sl.n[2]));
+                                const double lo = std::min(np_ + a * (nD - n1), np_ + b * (nD - n1)), hi = std::max(np_ + a * (nD + n1), np_ + b * (nD + n1));
+                                if (hi < sl.dmin || lo > sl.dmax) continue;  // the beam misses the slab inside the box
+                                clear = false;
+                            } else pending[np++] = e;
+                        }
+                        if (!clear) break;
+                        for (int q = np - 1; q >= 1; --q) stack.push_back(pending[q]);
+                        if (np > 0) { cur = pending[0]; continue; }
+                        if (stack.empty()) break;
+                        cur = stack.back(); stack.pop_back();
+                    }
+                    if (pass == 0) { out[7] += visits; if (clear) { out[2] += 1; out[3] += n_rays; } }
+                    else {
+                        out[8] += visits;
+                        if (clear) { out[4] += 1; out[5] += n_rays; if (n_occ) out[6] += 1; }
+                        else if (n_occ == 0) out[10] += n_rays;
+                    }
+                }
+                out[0] += 1; out[1] += n_rays; out[12] += n_occ;
+                if (n_occ == n_rays) out[11] += n_rays;
+            }
+        }
+    return 0;
+}
