@@ -232,6 +232,9 @@ constexpr int kLdsStackDepth = RTGO_LDS_STACK;
 #ifndef RTGO_VISIT_BATCH
 #define RTGO_VISIT_BATCH 4
 #endif
+#ifndef RTGO_BEAM_CAP
+#define RTGO_BEAM_CAP 32  // beam_is_clear(): block visits after which a beam's walk gives up (0: never).  With leaf slabs a walk no longer stops at the first leaf BOX it meets, and the longest of a wavefront's 64 walks sets its pace: frame 231.5 ms without a cap, 237.3 / 232.6 / 228.8 / 228.9 with 12 / 16 / 24 / 32 (k_pair_beam alone 28.9 -> 17 ms; 0.5 % fewer rays decided by beams at 32)
+#endif
 #ifndef RTGO_LEAF_SLAB
 #define RTGO_LEAF_SLAB 1  // occluded(), beam_is_clear(): leaves have a slab besides their box (0: A/B switch)
 #endif
@@ -424,8 +427,9 @@ RT_DEV bool ray_misses_leaf_slab(const float4 b0, const float4 b1, const float4 
     const float y0 = (b0.y - o.y) * inv.y, y1 = (b1.x - o.y) * inv.y;
     const float z0 = (b0.z - o.z) * inv.z, z1 = (b1.y - o.z) * inv.z;
     // a NaN (0 * inf) drops out of fmaxf / fminf: that axis then bounds nothing
-    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin)) * (1.0f - 4.0f * kSlabMargin);
-    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax)) * (1.0f + 4.0f * kSlabMargin);
+    const float tn0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+    const float tf0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+    const float tn = fmaf(-4.0f * kSlabMargin, fabsf(tn0), tn0), tf = fmaf(4.0f * kSlabMargin, fabsf(tf0), tf0);  // widened, whatever their signs
     const f3 n = mk3(b1.z, b1.w, b2.x);
     const f3 rel = mk3(o.x - b0.x, o.y - b0.y, o.z - b0.z);
     const float nob = dotf(n, rel), nd = dotf(n, d);
@@ -676,7 +680,7 @@ RT_DEV uint32_t beam_visit_qblock(const DScene& S, uint32_t blk, const Beam& bm,
     return ~miss & (h0.w >> 24);
 }
 // the beam against the EXACT box of child record `rec`
-// (*first_shape = the leaf's first shape, which is where its slab is filed; [*lo_out, *hi_out] = the beam's parameters inside the box)
+// (the walk without slabs, RTGO_SLAB=0; *first_shape = the leaf's first shape, [*lo_out, *hi_out] = the beam's parameters inside the box)
 RT_DEV bool beam_meets_record(const DScene& S, uint32_t rec, const Beam& bm, uint32_t* first_shape, float* lo_out, float* hi_out) {
     const float4 a = S.recs[2 * (size_t)rec], b = S.recs[2 * (size_t)rec + 1];  // {min.xyz, max.x}, {max.y, max.z, w0, w1}
     const bool nx = (bm.sign & 1u) != 0u, ny = (bm.sign & 2u) != 0u, nz = (bm.sign & 4u) != 0u;
@@ -688,20 +692,6 @@ RT_DEV bool beam_meets_record(const DScene& S, uint32_t rec, const Beam& bm, uin
     *first_shape = __float_as_uint(b.z) >> 8;
     *lo_out = lo; *hi_out = hi;
     return lo <= hi;
-}
-// true: no ray of the beam { p + s (D + j), |j_a| <= R } can be between the planes of leaf `first_shape`'s slab while
-// its parameter is inside [lo, hi] (where the beam is inside the leaf's box).  At parameter s the beam's points have
-// n . (x - box.min) within n . (p - box.min) + s (n . D -/+ R |n|_1): linear in s, so the ends of [lo, hi] bound it.
-RT_DEV bool beam_misses_leaf_slab(const DScene& S, uint32_t first_shape, f3 p, f3 D, float R, float lo, float hi) {
-    const float4 b0 = S.leaf_bound[3 * (size_t)first_shape], b1 = S.leaf_bound[3 * (size_t)first_shape + 1], b2 = S.leaf_bound[3 * (size_t)first_shape + 2];
-    const f3 n = mk3(b1.z, b1.w, b2.x);
-    const f3 rel = mk3(p.x - b0.x, p.y - b0.y, p.z - b0.z);
-    const float nob = dotf(n, rel), nD = dotf(n, D);
-    const float n1 = R * ((fabsf(n.x) + fabsf(n.y)) + fabsf(n.z));
-    const float a = lo * (1.0f - 64.0f * kSlabMargin), b = hi * (1.0f + 64.0f * kSlabMargin);  // lo >= s0 > 0
-    const float vlo = fminf(fmaf(a, nD - n1, nob), fmaf(b, nD - n1, nob)), vhi = fmaxf(fmaf(a, nD + n1, nob), fmaf(b, nD + n1, nob));
-    const float m = kSlabMargin * (((fabsf(rel.x) + fabsf(rel.y)) + fabsf(rel.z)) + b * (((fabsf(D.x) + fabsf(D.y)) + fabsf(D.z)) + 3.0f * R));
-    return vhi + m < b2.y || vlo - m > b2.z;
 }
 // true: no leaf box of the tree meets the beam.  Every lane of the wavefront calls it (live = this lane has a beam).
 // The walk goes over the quantised blocks (5 loads per visit); a leaf whose quantised box the beam meets is checked
@@ -716,14 +706,51 @@ RT_DEV bool beam_misses_leaf_slab(const DScene& S, uint32_t first_shape, f3 p, f
 constexpr int kResumeWords = 12;
 constexpr int kResumeStack = kLdsStackDepth < kResumeWords - 1 ? kLdsStackDepth : kResumeWords - 1;  // entries handed over at most
 constexpr uint32_t kResumeRoot = 0xffffffffu;
-// origin(&p, &D): the pair's point and light - point once more (only a beam that meets a leaf's box needs them again:
-// kept in registers through the walk they would be spilled).
-template <class F>
-RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, const Beam& bm, float R, F&& origin, uint32_t* cur_out, int* sp_out) {
+// The pair's point p and D = light - p wait in the lane's leaf-queue words of LDS (the beam walk queues no leaves), for
+// the few leaves whose box the beam meets: kept in registers through the walk they would be spilled.
+RT_DEV void beam_store_origin(const TraceStack& st, f3 p, f3 D) {
+    uint32_t* const w = st.lds + kLdsStackDepth * st.lds_stride;
+    w[0] = __float_as_uint(p.x); w[st.lds_stride] = __float_as_uint(p.y); w[2 * st.lds_stride] = __float_as_uint(p.z);
+    w[3 * st.lds_stride] = __float_as_uint(D.x); w[4 * st.lds_stride] = __float_as_uint(D.y); w[5 * st.lds_stride] = __float_as_uint(D.z);
+}
+static_assert(kPendCap >= 6, "beam_store_origin() uses six of the leaf-queue words");
+// The beam against a leaf's exact box and its slab as filed in DScene::leaf_bound (one fetch).  [lo, hi] = the beam's
+// parameters inside the box; no ray of the beam { p + s (D + j), |j_a| <= R } is between the slab's planes there if the
+// range of n . (x - box.min) over the beam's points misses [dmin, dmax]: at parameter s that range is
+// n . (p - box.min) + s (n . D -/+ R |n|_1), linear in s, so the two ends of [lo, hi] bound it.
+RT_DEV bool beam_meets_leaf(const DScene& S, const TraceStack& st, uint32_t first_shape, const Beam& bm, float R) {
+    const float4* const lb = S.leaf_bound + 3 * (size_t)first_shape;
+    const float4 a = lb[0], b = lb[1], c = lb[2];
+    const uint32_t* const w = st.lds + kLdsStackDepth * st.lds_stride;
+    const f3 p = mk3(__uint_as_float(w[0]), __uint_as_float(w[st.lds_stride]), __uint_as_float(w[2 * st.lds_stride]));
+    const f3 D = mk3(__uint_as_float(w[3 * st.lds_stride]), __uint_as_float(w[4 * st.lds_stride]), __uint_as_float(w[5 * st.lds_stride]));
+    const bool nx = (bm.sign & 1u) != 0u, ny = (bm.sign & 2u) != 0u, nz = (bm.sign & 4u) != 0u;
+    const float ex = fmaf(nx ? a.w : a.x, bm.inv_n.x, bm.c_n.x), xx = fmaf(nx ? a.x : a.w, bm.inv_f.x, bm.c_f.x);
+    const float ey = fmaf(ny ? b.x : a.y, bm.inv_n.y, bm.c_n.y), xy = fmaf(ny ? a.y : b.x, bm.inv_f.y, bm.c_f.y);
+    const float ez = fmaf(nz ? b.y : a.z, bm.inv_n.z, bm.c_n.z), xz = fmaf(nz ? a.z : b.y, bm.inv_f.z, bm.c_f.z);
+    const float lo = fmaxf(fmaxf(ex, ey), fmaxf(ez, bm.s0));
+    const float hi = fminf(fminf(xx, xy), fminf(xz, bm.s1));
+    if (!(lo <= hi)) return false;
+    const f3 n = mk3(b.z, b.w, c.x);
+    const f3 rel = mk3(p.x - a.x, p.y - a.y, p.z - a.z);
+    const float nob = dotf(n, rel), nD = dotf(n, D);
+    const float n1 = R * ((fabsf(n.x) + fabsf(n.y)) + fabsf(n.z));
+    const float s_a = lo * (1.0f - 64.0f * kSlabMargin), s_b = hi * (1.0f + 64.0f * kSlabMargin);  // lo >= s0 > 0
+    const float vlo = fminf(fmaf(s_a, nD - n1, nob), fmaf(s_b, nD - n1, nob)), vhi = fmaxf(fmaf(s_a, nD + n1, nob), fmaf(s_b, nD + n1, nob));
+    const float m = kSlabMargin * (((fabsf(rel.x) + fabsf(rel.y)) + fabsf(rel.z)) + s_b * (((fabsf(D.x) + fabsf(D.y)) + fabsf(D.z)) + 3.0f * R));
+    return !(vhi + m < c.y || vlo - m > c.z);
+}
+RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, const Beam& bm, float R, uint32_t* cur_out, int* sp_out) {
     uint32_t cur = 0u;  // block index; the root is block 0
     int sp = 0;
     bool walking = live, clear = true;
+#if RTGO_BEAM_CAP > 0
+    int budget = RTGO_BEAM_CAP;  // block visits after which a walk gives up: the pair's rays then resume at the block it was about to enter
+#endif
     while (__ballot(walking) != 0ull) {
+#if RTGO_BEAM_CAP > 0
+        if (walking && budget-- == 0) { clear = false; walking = false; }
+#endif
         if (walking) {
             uint4 h1;
             uint32_t present;
@@ -731,18 +758,25 @@ RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, cons
             uint32_t leaf_hits = hit & (h1.x >> 24);
             bool met = false;
             if (leaf_hits) {
-                const uint32_t first = S.block_first[cur];
-                f3 p = mk3(0.0f, 0.0f, 0.0f), D = p;
-                bool have = false;
-                while (leaf_hits && !met) {
-                    const int k = __ffs((int)leaf_hits) - 1;
-                    leaf_hits &= leaf_hits - 1u;
-                    uint32_t first_shape;
-                    float lo, hi;
-                    met = beam_meets_record(S, first + (uint32_t)__popc(present & ((1u << k) - 1u)), bm, &first_shape, &lo, &hi);
-                    if (met && S.leaf_bound) {  // inside the leaf's box, but between the planes of its slab there?
-                        if (!have) { origin(&p, &D); have = true; }
-                        met = !beam_misses_leaf_slab(S, first_shape, p, D, R, lo, hi);
+                if (S.leaf_bound) {
+                    // a leaf's first shape as in queue_qleaves(): the block's first leaf shape + the counts of the leaves before it
+                    const uint32_t c_lo = h1.z & 0x1f1f1f1fu, c_hi = h1.w & 0x1f1f1f1fu;
+                    uint32_t i_lo = c_lo + (c_lo << 8); i_lo += i_lo << 16;
+                    uint32_t i_hi = c_hi + (c_hi << 8); i_hi += i_hi << 16;
+                    const uint32_t p_lo = i_lo << 8, p_hi = (i_hi << 8) + (i_lo >> 24) * 0x01010101u;
+                    while (leaf_hits && !met) {
+                        const int k = __ffs((int)leaf_hits) - 1;
+                        leaf_hits &= leaf_hits - 1u;
+                        met = beam_meets_leaf(S, st, h1.y + (((k < 4 ? p_lo : p_hi) >> ((uint32_t)(k & 3) * 8u)) & 0xffu), bm, R);
+                    }
+                } else {
+                    const uint32_t first = S.block_first[cur];
+                    while (leaf_hits && !met) {
+                        const int k = __ffs((int)leaf_hits) - 1;
+                        leaf_hits &= leaf_hits - 1u;
+                        uint32_t first_shape;
+                        float lo, hi;
+                        met = beam_meets_record(S, first + (uint32_t)__popc(present & ((1u << k) - 1u)), bm, &first_shape, &lo, &hi);
                     }
                 }
             }
@@ -888,6 +922,7 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
                 const float tmx = __shfl(tmax, owner);
                 const float tmn = SAME_TMIN ? tmin : __shfl(tmin, owner);
                 if (item < ltotal) {
+                    RT_PROF_POINT(3);  // leaf slab tests
                     uint32_t* const slot = oq + (item - first_excl) * st.lds_stride;
                     const uint32_t leaf = *slot;
                     const float4* const lb = S.leaf_bound + 3 * (size_t)(leaf >> 8);

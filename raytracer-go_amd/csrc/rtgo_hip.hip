@@ -546,19 +546,14 @@ __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S,
             const f3 p = add3(mk3(ro.x, ro.y, ro.z), scale3(ro.w, mk3(rdv.x, rdv.y, rdv.z)));
             const DLight& L = S.pos_lights[lp];
             judge = surely_inside_cone(L, p);
-            if (judge) bm = make_beam(p, ld3(L.pos), kBeamR, 0.01f);
+            if (judge) {
+                bm = make_beam(p, ld3(L.pos), kBeamR, 0.01f);
+                beam_store_origin(st, p, sub3(ld3(L.pos), p));
+            }
         }
         uint32_t stop_block = 0;
         int stop_sp = 0;
-        // (the pair's point and light once more, for the few leaves whose box the beam meets: not kept across the walk)
-        const auto origin = [&](f3* p_out, f3* D_out) {
-            const uint32_t slot = Wk.phong_queue[hit_i];
-            const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
-            const f3 p = add3(mk3(ro.x, ro.y, ro.z), scale3(ro.w, mk3(rdv.x, rdv.y, rdv.z)));
-            *p_out = p;
-            *D_out = sub3(ld3(S.pos_lights[lp].pos), p);
-        };
-        const bool clear = beam_is_clear(S, st, judge, bm, kBeamR, origin, &stop_block, &stop_sp) && judge;
+        const bool clear = beam_is_clear(S, st, judge, bm, kBeamR, &stop_block, &stop_sp) && judge;
         if (clear) {
             Wk.vis[(size_t)hit_i * S.n_pos_lights + lp] = (uint32_t)B.reps;
             decided += (unsigned long long)B.reps;
@@ -1706,6 +1701,12 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
     // a walk through two blocks is cheaper than proving it unnecessary) and 4 repetitions or more (a beam's walk costs
     // about a ray's: config 2 at 1080p 16 spp with 1 repetition 9.1 ms without, 10.1 with; with 16 repetitions 20.4 and
     // 15.7).  RTGO_BEAM=0 / 1 forces them off / on.
+    // RTGO_SLAB=0 at render time: the shadow kernels of this call ignore the leaves' slabs (A/B switch, like RTGO_BEAM)
+    DScene shadow_scene = s->d;
+    {
+        const char* slab_env = std::getenv("RTGO_SLAB");
+        if (slab_env && slab_env[0] == '0') shadow_scene.leaf_bound = nullptr;
+    }
     const char* beam_env = std::getenv("RTGO_BEAM");
     const bool beams = beam_env ? beam_env[0] != '0' : (s->info.n_shapes >= 256 && reps >= 4);
     const char* resume_env = std::getenv("RTGO_RESUME");  // "0": rays start at the root, not where their pair's beam stopped (A/B switch)
@@ -1778,17 +1779,17 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
                         const uint32_t* queue_len = pair_counter;
                         const uint32_t* resume = nullptr;
                         if (beams) {  // pairs whose rays one conservative walk proves unoccluded never reach k_shadow
-                            hipLaunchKernelGGL(k_pair_beam, dim3(grid_for(n_pairs, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, B, wk, n_phong, pair_counter);
+                            hipLaunchKernelGGL(k_pair_beam, dim3(grid_for(n_pairs, arena.grid_cap)), dim3(kBlock), 0, stream, shadow_scene, B, wk, n_phong, pair_counter);
                             queue = wk.pair_seg;
                             queue_len = wk.light_count + 2 * L;
                             resume = resume_on ? wk.beam_state : nullptr;
                         }
                         if (staged) ss.a = stamp();  // ms_shadow brackets k_shadow alone
                         if (reps > 64)
-                            hipLaunchKernelGGL(k_shadow<true>, dim3(grid_for(n_pairs * P.group, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, B, wk, n_phong, b,
+                            hipLaunchKernelGGL(k_shadow<true>, dim3(grid_for(n_pairs * P.group, arena.grid_cap)), dim3(kBlock), 0, stream, shadow_scene, B, wk, n_phong, b,
                                                P.group, P.group_shift, queue, queue_len, resume);
                         else
-                            hipLaunchKernelGGL(k_shadow<false>, dim3(grid_for(n_pairs * P.group, arena.grid_cap)), dim3(kBlock), 0, stream, s->d, B, wk, n_phong, b,
+                            hipLaunchKernelGGL(k_shadow<false>, dim3(grid_for(n_pairs * P.group, arena.grid_cap)), dim3(kBlock), 0, stream, shadow_scene, B, wk, n_phong, b,
                                                P.group, P.group_shift, queue, queue_len, resume);
                         if (staged) ss.b = stamp();
                     }
@@ -2013,7 +2014,12 @@ static int rt_trace_rays_impl(rt_scene* s, const float* rays, int64_t n, int32_t
     HIP_TRY(s->probe_out.ensure((size_t)n * sizeof(int)));
     HIP_TRY(s->probe_out2.ensure((size_t)n * sizeof(float)));
     HIP_TRY(hipMemcpy(s->probe_in.p, rays, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_trace_probe, dim3(grid_for((unsigned long long)n, s->lanes[0].arena.grid_cap)), dim3(kBlock), 0, nullptr, s->d, s->lanes[0].arena.wk,
+    DScene probe_scene = s->d;
+    {
+        const char* slab_env = std::getenv("RTGO_SLAB");  // "0": the any-hit walks of this call ignore the leaves' slabs
+        if (slab_env && slab_env[0] == '0') probe_scene.leaf_bound = nullptr;
+    }
+    hipLaunchKernelGGL(k_trace_probe, dim3(grid_for((unsigned long long)n, s->lanes[0].arena.grid_cap)), dim3(kBlock), 0, nullptr, probe_scene, s->lanes[0].arena.wk,
                        (const float*)s->probe_in.p, (uint32_t)n, any_hit, (int*)s->probe_out.p, (float*)s->probe_out2.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(prim_out, s->probe_out.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
@@ -2259,7 +2265,8 @@ int rt_multi_get_info(const rt_multi* m, rt_multi_info* out) {
 const char* rt_build_info(void) {
     return "src=" RTGO_SRC_HASH " shadow_waves=" RTGO_STR(RTGO_SHADOW_WAVES) " beam_waves=" RTGO_STR(RTGO_BEAM_WAVES)
            " extend_waves=" RTGO_STR(RTGO_EXTEND_WAVES) " lds_stack=" RTGO_STR(RTGO_LDS_STACK) " pend_cap=" RTGO_STR(RTGO_PEND_CAP)
-           " flush_lanes=" RTGO_STR(RTGO_FLUSH_LANES) " steal=" RTGO_STR(RTGO_STEAL) " visit_batch=" RTGO_STR(RTGO_VISIT_BATCH) " max_grid=" RTGO_STR(RTGO_MAX_GRID);
+           " flush_lanes=" RTGO_STR(RTGO_FLUSH_LANES) " steal=" RTGO_STR(RTGO_STEAL) " visit_batch=" RTGO_STR(RTGO_VISIT_BATCH) " max_grid=" RTGO_STR(RTGO_MAX_GRID)
+           " leaf_slab=" RTGO_STR(RTGO_LEAF_SLAB) " beam_cap=" RTGO_STR(RTGO_BEAM_CAP);
 }
 
 #ifdef RTGO_PROF

@@ -17,7 +17,9 @@ v = list(out)
 # points 0/1 also count the primary rays' traversal (k_extend): 3 % of the rays at config 3
 rounds = v[4]
 print("shadow rays", st.rays_shadow, "ms_shadow %.1f" % st.ms_shadow, "wave rounds", rounds, "lanes/round %.1f" % (v[5] / max(1, rounds)))
-for name, i in (("block visits", 0), ("shape tests", 1)):
+for name, i in (("block visits", 0), ("shape tests", 1), ("leaf slabs", 3)):
+    if not v[2 * i]:
+        continue
     print("%-12s: %.1f per wave round, %.1f per ray, lane utilisation %.2f" %
           (name, v[2 * i] / rounds, v[2 * i + 1] / st.rays_shadow, v[2 * i + 1] / (64.0 * v[2 * i])))
 it = v[8]

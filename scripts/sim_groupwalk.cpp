@@ -1001,6 +1001,7 @@ extern "C" int sim_leaf_slab(const orc_scene* s, const rt_image_spec* spec, uint
     if (root->as_leaf) return 0;
     struct Slab { double n[3], dmin, dmax; bool any; };
     std::unordered_map<Node*, Slab> slabs;
+    const int inner_max = std::getenv("SIM_INNER_MAX") ? std::atoi(std::getenv("SIM_INNER_MAX")) : 64;  // mode 2: inner children with at most this many shapes get a slab too
     static const double dirs[10][3] = {{1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}, {1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1}};
     auto slab_of = [&](Node* lf) -> const Slab& {
         auto it = slabs.find(lf);
@@ -1026,7 +1027,7 @@ extern "C" int sim_leaf_slab(const orc_scene* s, const rt_image_spec* spec, uint
                 *lo = 1e300; *hi = -1e300;
                 for (auto& p : pts) { const double v = n[0] * p[0] + n[1] * p[1] + n[2] * p[2]; *lo = std::min(*lo, v); *hi = std::max(*hi, v); }
             };
-            if (mode == 0) {
+            if (mode != 1) {
                 const double len = std::sqrt(nsum[0] * nsum[0] + nsum[1] * nsum[1] + nsum[2] * nsum[2]);
                 if (len > 0) { for (int k = 0; k < 3; ++k) sl.n[k] = nsum[k] / len; span(sl.n, &sl.dmin, &sl.dmax); } else sl.any = false;
             } else {
@@ -1062,6 +1063,16 @@ extern "C" int sim_leaf_slab(const orc_scene* s, const rt_image_spec* spec, uint
                     if (t1 == t1) tf = std::min(tf, t1);
                 }
                 if (!(tn <= tf)) continue;
+                if (!e->as_leaf && use_slab && mode >= 2 && e->count <= inner_max) {
+                    c[4] += 1;
+                    const Slab& sl = slab_of(e);
+                    if (sl.any) {
+                        const double so = sl.n[0] * r.p.x + sl.n[1] * r.p.y + sl.n[2] * r.p.z, sd = sl.n[0] * r.d.x + sl.n[1] * r.d.y + sl.n[2] * r.d.z;
+                        const double a0 = so + (double)tn * sd, a1 = so + (double)tf * sd;
+                        const double m = 1e-5 * (std::fabs(a0) + std::fabs(a1));
+                        if (std::max(a0, a1) + m < sl.dmin || std::min(a0, a1) - m > sl.dmax) continue;
+                    }
+                }
                 if (e->as_leaf) {
                     c[1] += 1;
                     if (use_slab) {
@@ -1137,7 +1148,7 @@ extern "C" int sim_leaf_slab(const orc_scene* s, const rt_image_spec* spec, uint
 // [7] beam visits without slabs, [8] beam visits with slabs (walks go on past leaves whose slab is missed),
 // [9] leaf boxes met by beams in the slab walk, [10] rays of pairs that are not clear with slabs but whose rays are all unoccluded,
 // [11] rays of pairs with all rays occluded, [12] occluded rays
-extern "C" int sim_ball_beam_slab(const orc_scene* s, const rt_image_spec* spec, uint64_t seed, double R, double* out) {
+extern "C" int sim_ball_beam_slab(const orc_scene* s, const rt_image_spec* spec, uint64_t seed, double R, double* out, double* hist) {
     const Scene& sc = s->sc;
     const int W = spec->width, H = spec->height, reps = spec->soft_shadow_monte_carlo_repetitions;
     const CameraF64 c64 = new_camera(sc, W, H);
@@ -1258,6 +1269,7 @@ extern "C" int sim_ball_beam_slab(const orc_scene* s, const rt_image_spec* spec,
                     }
                     if (pass == 0) { out[7] += visits; if (clear) { out[2] += 1; out[3] += n_rays; } }
                     else {
+                        if (hist) { const int b = std::min(63, (int)visits); hist[(clear ? 0 : 64) + b] += 1; hist[128 + b] += clear ? n_rays : 0; }
                         out[8] += visits;
                         if (clear) { out[4] += 1; out[5] += n_rays; if (n_occ) out[6] += 1; }
                         else if (n_occ == 0) out[10] += n_rays;

@@ -330,14 +330,16 @@ def test_two_host_threads_create_and_render_at_once(backend, rt, c1):
 
 def test_full_size_frame_equals_the_plain_path(backend, scenes, monkeypatch):
     """BASELINE's headline frame at its full size (config 3: 871,210 shapes, 1920x1080, 64 spp, 16 repetitions): what
-    the default path renders — pair beams, rays resumed from their beams, four lanes — is bit for bit the accumulation
-    buffer of the plain path (every shadow ray walked from the root, one lane), with the same ray counts."""
+    the default path renders — pair beams, rays resumed from their beams, leaf slabs, four lanes — is bit for bit the
+    accumulation buffer of the plain path (every shadow ray walked from the root, every shape of every leaf whose box it
+    meets tested, one lane), with the same ray counts."""
     spec, scene = scenes.config3(1920, 1080, 64, 16)
     keys = ("paths", "rays_primary", "rays_continuation", "rays_shadow", "phong_hits")
     with backend.DeviceScene(scene) as dev:
         a, sa = dev.render_accum(spec)
         monkeypatch.setenv("RTGO_BEAM", "0")
         monkeypatch.setenv("RTGO_LANES", "1")
+        monkeypatch.setenv("RTGO_SLAB", "0")
         b, sb = dev.render_accum(spec)
     assert sa.rays_shadow_beam > 0.4 * sa.rays_shadow and sb.rays_shadow_beam == 0
     assert sa.paths == 1920 * 1080 * 64

@@ -192,3 +192,78 @@ def test_headline_frame_size_against_float64_reference(backend, bridge, scenes, 
     assert ctr["rays_primary"] == (r1 - r0) * spec.Width
     assert within >= 0.985
     assert (d32 <= 1e-3).mean() >= 0.999
+
+
+def test_leaf_slabs_change_no_answer(backend, rt, scenes, gold_dir, monkeypatch):
+    """Every leaf has a slab besides its box (device_math.hpp "leaf slabs"): a ray tests a leaf's shapes only where it
+    is inside the box AND between the slab's planes, and a pair's beam goes on past a leaf whose slab it misses.  Both
+    only ever say "cannot hit", so with RTGO_SLAB=0 (no slabs: every shape of every leaf met is tested) the
+    accumulation buffer and every counter but the beams' share must be identical: on config 3 and config 5 (curved
+    meshes, glass, a mirror), and on seeded scenes built to strain the margins — smooth bumpy sheets (thin slabs) seen at
+    grazing angles, at the origin and 1000 / 10^4 units away, with spheres, slivers and zero-area triangles among the
+    leaves; explicit any-hit rays (rt_trace_rays) through the big mesh answer alike as well."""
+    api = rt
+    cases = []
+    spec3, scene3 = scenes.config3(240, 135, 4, 16, asset_dir=gold_dir)
+    cases.append(("config 3", spec3, scene3))
+    spec5, scene5 = scenes.config5(240, 135, 2, 16)
+    cases.append(("config 5", spec5, scene5))
+    for seed, off in enumerate(([0.0, 0.0, 0.0], [1000.0, -500.0, 250.0], [1e4, 1e4, -1e4])):
+        rng = np.random.default_rng(700 + seed)
+        o = np.array(off)
+        n = 96
+        u, v = np.meshgrid(np.linspace(-3, 3, n), np.linspace(-3, 3, n), indexing="ij")
+        y = 1.2 + 0.25 * np.sin(1.7 * u) * np.cos(1.3 * v) + 0.02 * rng.normal(size=u.shape)
+        P = np.stack([u, y, v], axis=-1) + o
+        a, b, c, d = P[:-1, :-1], P[1:, :-1], P[:-1, 1:], P[1:, 1:]
+        tri = np.concatenate([np.stack([a, b, c], axis=-2).reshape(-1, 3, 3), np.stack([d, c, b], axis=-2).reshape(-1, 3, 3)])
+        tri = np.concatenate([tri, np.repeat(P[5, 5][None, None, :], 3, axis=1) + np.zeros((4, 3, 3)),  # zero-area triangles
+                              (P[10, 10] + np.array([[0, 0.5, 0], [1e-4, 0.5, 0], [0, 1.5, 1e-4]]))[None]])  # a sliver
+        mat = api.PhongBlinn(ColorFrac=api.Vec(0.8, 0.7, 0.6), SpecularColorFrac=api.Vec(1, 1, 1), SpecHardness=16)
+        floor = api.PhongBlinn(ColorFrac=api.Vec(0.6, 0.6, 0.6), SpecularColorFrac=api.Vec(0.3, 0.3, 0.3), SpecHardness=4)
+        V = lambda x, y_, z: api.Vec(float(x + o[0]), float(y_ + o[1]), float(z + o[2]))
+        R = 9.0
+        shapes = [api.TrianglePlane(V(-R, 0, -R), V(-R, 0, R), V(R, 0, -R), False, floor),
+                  api.TrianglePlane(V(R, 0, R), V(R, 0, -R), V(-R, 0, R), False, floor),
+                  api.TriangleMesh(tri, False, mat)]
+        for k in range(6):
+            p = rng.uniform(-2.5, 2.5, 3)
+            shapes.append(api.Sphere(V(p[0], 1.3 + 0.1 * k, p[2]), float(rng.uniform(0.05, 0.3)), mat))
+        lights = [api.AmbientLight(api.Vec(1, 1, 1), 0.05),
+                  api.PointLight(ColorFrac=api.Vec(1, 1, 1), Position=V(6, 2.0, -5), LightIntensity=60, SpecularLightIntensity=20,
+                                 InverseSquareLawDecayFactor=0.5),  # low: its rays graze the sheet
+                  api.SpotLight(ColorFrac=api.Vec(0.8, 0.9, 1), Position=V(-1, 6, 1), LightIntensity=40, SpecularLightIntensity=10,
+                                LookAt=V(0, 1, 0), Angle=40.0, InverseSquareLawDecayFactor=0.3)]
+        spec = api.ImageSpec(200, 120, 3, 4, 16, 16, api.Dijkstra)
+        scene = api.Scene(V(0, 2.2, -7), V(0, 1.2, 0), api.Vec(0, 1, 0), V(0, 1.2, 0), 0.02, 50.0, shapes, lights)
+        cases.append((f"sheet at {off}", spec, scene))
+    keys = ("paths", "rays_primary", "rays_continuation", "rays_shadow", "phong_hits", "rays_shadow_reference_equivalent")
+    for name, spec, scene in cases:
+        with backend.DeviceScene(scene) as dev:
+            monkeypatch.setenv("RTGO_BEAM", "1")
+            got, st = dev.render_accum(spec)
+            monkeypatch.setenv("RTGO_SLAB", "0")
+            want, st0 = dev.render_accum(spec)
+            monkeypatch.setenv("RTGO_BEAM", "0")
+            plain, st1 = dev.render_accum(spec)
+            monkeypatch.delenv("RTGO_SLAB")
+            slab_only, st2 = dev.render_accum(spec)  # slabs in the rays' shape loop, no beams
+            monkeypatch.delenv("RTGO_BEAM")
+            if name == "config 3":  # 200,000 explicit any-hit rays through the big mesh, with and without slabs
+                rng = np.random.default_rng(5)
+                o = rng.uniform(-2.0, 2.0, (200_000, 3)) + np.array([0.0, 1.0, 0.0])
+                d = rng.normal(size=(200_000, 3))
+                d /= np.linalg.norm(d, axis=1, keepdims=True)
+                rays = np.concatenate([o, d, np.full((len(o), 1), 0.01), np.full((len(o), 1), 6.0)], axis=1).astype(np.float32)
+                ids_a, _ = dev.trace_rays(rays, any_hit=True, uniform_tmin=True)
+                monkeypatch.setenv("RTGO_SLAB", "0")
+                ids_b, _ = dev.trace_rays(rays, any_hit=True, uniform_tmin=True)
+                monkeypatch.delenv("RTGO_SLAB")
+                assert np.array_equal(ids_a > 0, ids_b > 0), int(((ids_a > 0) != (ids_b > 0)).sum())
+                assert 0.02 < (ids_a > 0).mean() < 0.98, float((ids_a > 0).mean())
+        print(f"{name}: beams decide {st.rays_shadow_beam} of {st.rays_shadow} shadow rays with slabs, {st0.rays_shadow_beam} without")
+        assert np.array_equal(got, want) and np.array_equal(got, plain) and np.array_equal(got, slab_only), \
+            (name, float(np.abs(got - want).max()), float(np.abs(got - plain).max()), float(np.abs(got - slab_only).max()))
+        for k in keys:
+            assert getattr(st, k) == getattr(st0, k) == getattr(st1, k) == getattr(st2, k), (name, k)
+        assert st.rays_shadow_beam >= st0.rays_shadow_beam and st1.rays_shadow_beam == 0 and st2.rays_shadow_beam == 0
