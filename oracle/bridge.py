@@ -86,7 +86,7 @@ class OracleScene:
         # F32_STACK mirrors the device tree: same shapes-per-leaf rule as the device flattener
         octree = os.environ.get("RTGO_TREE") == "octree"
         lib().orc_set_tree(self._h, 0 if octree else 1)
-        lib().orc_set_leaf_size(self._h, int(os.environ.get("RTGO_LEAF_SIZE", "4" if octree else "6")))
+        lib().orc_set_leaf_size(self._h, int(os.environ.get("RTGO_LEAF_SIZE", "4" if octree else "20")))
 
     def close(self):
         if self._h:

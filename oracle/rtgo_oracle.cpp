@@ -359,8 +359,8 @@ inline double node_area(const Node* n) {
     return 2.0 * ((dx * dy + dy * dz) + dz * dx);
 }
 // The device flattener's leaf rule (csrc/octree.cpp is_leaf), restated: at most leaf_size shapes, and the box either
-// small (less than 1/64 of the area of the scene's box) or tight (at most 1.5 x the area of the largest single-shape
-// box in it); a subtree of few but disparate large shapes stays a block of smaller leaves.
+// small (less than 1/64 of the area of the scene's box) or, for at most 6 shapes, tight (at most 1.5 x the area of the
+// largest single-shape box in it); a subtree of few but disparate large shapes stays a block of smaller leaves.
 double max_shape_area(const Node* n) {
     if (n->leaf) return n->shape >= 0 ? node_area(n) : 0.0;
     double m = 0;
@@ -373,7 +373,7 @@ void mark_leaves(Node* n, int leaf_size, double root_area) {
         if (n->count <= 1 || n->leaf) n->as_leaf = true;
         else {
             const double a = node_area(n);
-            n->as_leaf = a * 64.0 < root_area || a <= 1.5 * max_shape_area(n);
+            n->as_leaf = a * 64.0 < root_area || (n->count <= 6 && a <= 1.5 * max_shape_area(n));  // tight boxes only for leaves of at most 6 shapes
         }
     }
     if (!n->leaf)

@@ -418,7 +418,7 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
 // 0.1 shapes, and a pair's beam (below) that meets a leaf's box but not its slab there goes on: 64 % instead of 53 %
 // of the shadow rays belong to pairs that a beam proves clear.  The tests only ever say "cannot hit" with margins
 // (2^-16 of the distances involved, against float32 rounding of 2^-23 in the shape tests), so the answers are the
-// ones the shape tests alone would give; a leaf that holds a sphere has no slab (n = 0, dmin = -inf, dmax = +inf).
+// ones the shape tests alone would give; a sphere in a leaf adds its extent along n; a leaf of spheres only has no slab (n = 0, dmin = -inf, dmax = +inf).
 constexpr float kSlabMargin = 1.52587890625e-05f;  // 2^-16
 // true: the ray cannot hit a shape of the leaf.  Box interval in local coordinates ((plane - o) * inv: a rounding
 // error relative to the distance, not to |o|), never used to cull by itself; the slab is evaluated at its two ends.

@@ -736,6 +736,7 @@ static double box_area(const HostNode& n) {
 // of the scene's box becomes a leaf only if that box is hardly larger (x 1.5 in area) than the largest box of a single
 // shape in it — two triangles of one wall — and is otherwise kept as a block of smaller leaves, whose flat boxes
 // nearly every ray misses.  Mirrored by the oracle (rtgo_oracle.cpp mark_leaves).
+constexpr int kTightLeafMax = 6;
 struct LeafRule {
     int leaf_size;
     double root_area;
@@ -753,7 +754,11 @@ static bool is_leaf(const HostNodes& nodes, int32_t e, const LeafRule& rule) {
     if (nodes[e].n_shapes <= 1 || nodes[e].child_base < 0) return true;
     const double a = box_area(nodes[e]);
     if (a * 64.0 < rule.root_area) return true;
-    return a <= 1.5 * max_shape_area(nodes, e);
+    // (a tight box makes a leaf of a few large shapes, two triangles of a wall; the many shapes of a wide leaf — leaf
+    // sizes above 6 pay because a leaf's slab, device_math.hpp, rejects nearly every ray that meets its box and not its
+    // surface — must be a small patch: the 11 shapes of the reference's example scene, spheres over a floor whose box is
+    // the scene's, would otherwise be ONE leaf that every ray and every pair's beam meets)
+    return nodes[e].n_shapes <= kTightLeafMax && a <= 1.5 * max_shape_area(nodes, e);
 }
 
 static void block_slots(const HostNodes& nodes, int32_t x, const LeafRule& rule, int32_t slot[8]) {

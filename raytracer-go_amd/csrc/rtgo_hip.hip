@@ -44,7 +44,9 @@ constexpr int kBlock = 256;
 #endif
 constexpr int kMaxGridBlocks = RTGO_MAX_GRID;  // grid-stride kernels; k_shadow ms per frame at config 3: 1024 -> 708, 2048 -> 688, 4096 -> 666, 8192 -> 651, 16384 -> 634, 65536 -> 636
 constexpr int64_t kDefaultMaxPaths = (int64_t)1 << 23;
-constexpr int kDefaultLeafSizeSah = 6;  // measured on config 3 (k_shadow ms per frame): 2 -> 833, 3 -> 816, 4 -> 823, 6 -> 791, 8 -> 809
+constexpr int kDefaultLeafSizeSah = 20;  // shapes per leaf (the SAH builder splits down to 8, the flattener makes one leaf of a subtree of at most this many).
+// Frame ms at config 3 with leaf slabs, which make a leaf that is met but not hit nearly free: 4 -> 245.9, 6 -> 228.1, 8 -> 223.6, 12 -> 218.7, 16 -> 216.0, 20 -> 214.3, 24 -> 214.7, 31 -> 220.4;
+// before them 6 was best (k_shadow ms: 2 -> 833, 3 -> 816, 4 -> 823, 6 -> 791, 8 -> 809 in round 1; 4 -> 257, 6 -> 250.6, 8 -> 252.7, 12 -> 254.7 at the start of round 3)
 constexpr int kDefaultLeafSize = 4;  // measured on config 3: 1 -> 2.84 s, 2 -> 2.58 s, 4 -> 2.42 s, 8 -> 2.48 s, 16 -> 2.76 s per frame
 
 thread_local std::string g_err;
@@ -588,8 +590,9 @@ __global__ void k_sum_counters(unsigned long long* fc) {
 // Scene set-up: one thread per child record; a leaf's record files the leaf's exact box and its slab under the leaf's
 // first shape (DScene::leaf_bound, device_math.hpp "leaf slabs").  n = the mean of the leaf's triangle normals (each
 // turned to the side of the first), narrowed to float32; dmin / dmax = the range of n . (vertex - box.min) over the
-// leaf's vertices in float64 with that float32 n, widened by 2^-16 of the box's size and rounded outward.  A leaf
-// with a sphere, or whose normals cancel, gets n = 0 and [-inf, +inf]: it is never culled.
+// leaf's vertices in float64 with that float32 n, widened by 2^-16 of the box's size and rounded outward.  A sphere
+// of the leaf adds its extent along n (centre -/+ radius) and no normal; a leaf of spheres only, or whose normals cancel,
+// gets n = 0 and [-inf, +inf]: it is never culled.
 __global__ __launch_bounds__(kBlock) void k_leaf_bounds(const float4* recs, const float4* prims, uint32_t n_recs, float4* leaf_bound) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_recs) return;
@@ -598,10 +601,9 @@ __global__ __launch_bounds__(kBlock) void k_leaf_bounds(const float4* recs, cons
     if (!(w1 & kLeafFlag)) return;
     const uint32_t first = w0 >> 8, count = w0 & 0xffu;
     double ns[3] = {0.0, 0.0, 0.0};
-    bool flat = true;
     for (uint32_t k = 0; k < count; ++k) {
         const float4 p0 = prims[3 * (size_t)(first + k)], p1 = prims[3 * (size_t)(first + k) + 1], p2 = prims[3 * (size_t)(first + k) + 2];
-        if (!(__float_as_uint(p2.y) & kPrimTriangle)) { flat = false; break; }
+        if (!(__float_as_uint(p2.y) & kPrimTriangle)) continue;  // a sphere: no normal of its own, its extent is added below
         const double e1[3] = {(double)p0.w - p0.x, (double)p1.x - p0.y, (double)p1.y - p0.z}, e2[3] = {(double)p1.z - p0.x, (double)p1.w - p0.y, (double)p2.x - p0.z};
         double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
         if (n[0] * ns[0] + n[1] * ns[1] + n[2] * ns[2] < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
@@ -610,11 +612,17 @@ __global__ __launch_bounds__(kBlock) void k_leaf_bounds(const float4* recs, cons
     const double len = sqrt(ns[0] * ns[0] + ns[1] * ns[1] + ns[2] * ns[2]);
     float nf[3] = {0.0f, 0.0f, 0.0f};
     float dmin = -__builtin_inff(), dmax = __builtin_inff();
-    if (flat && len > 0.0 && len < 1e300) {
+    if (len > 0.0 && len < 1e300) {
         for (int k = 0; k < 3; ++k) nf[k] = (float)(ns[k] / len);
         double lo = 1e300, hi = -1e300;
         for (uint32_t k = 0; k < count; ++k) {
             const float4 p0 = prims[3 * (size_t)(first + k)], p1 = prims[3 * (size_t)(first + k) + 1], p2 = prims[3 * (size_t)(first + k) + 2];
+            if (!(__float_as_uint(p2.y) & kPrimTriangle)) {  // sphere {centre, radius}: n . (centre - box.min) -/+ radius |n|, |n| <= 1 + 2^-22
+                const double t = ((double)nf[0] * ((double)p0.x - (double)a.x) + (double)nf[1] * ((double)p0.y - (double)a.y)) + (double)nf[2] * ((double)p0.z - (double)a.z);
+                const double r = fabs((double)p0.w) * 1.000001;
+                lo = t - r < lo ? t - r : lo; hi = t + r > hi ? t + r : hi;
+                continue;
+            }
             const double v[3][3] = {{p0.x, p0.y, p0.z}, {p0.w, p1.x, p1.y}, {p1.z, p1.w, p2.x}};
             for (int q = 0; q < 3; ++q) {
                 const double t = ((double)nf[0] * (v[q][0] - (double)a.x) + (double)nf[1] * (v[q][1] - (double)a.y)) + (double)nf[2] * (v[q][2] - (double)a.z);
