@@ -717,7 +717,7 @@ static_assert(kPendCap >= 6, "beam_store_origin() uses six of the leaf-queue wor
 // The beam against a leaf's exact box and its slab as filed in DScene::leaf_bound (one fetch).  [lo, hi] = the beam's
 // parameters inside the box; no ray of the beam { p + s (D + j), |j_a| <= R } is between the slab's planes there if the
 // range of n . (x - box.min) over the beam's points misses [dmin, dmax]: at parameter s that range is
-// n . (p - box.min) + s (n . D -/+ R |n|_1), linear in s, so the two ends of [lo, hi] bound it.
+// n . (p - box.min) + s (n . D -/+ R |n|_2), linear in s, so the two ends of [lo, hi] bound it.
 RT_DEV bool beam_meets_leaf(const DScene& S, const TraceStack& st, uint32_t first_shape, const Beam& bm, float R) {
     const float4* const lb = S.leaf_bound + 3 * (size_t)first_shape;
     const float4 a = lb[0], b = lb[1], c = lb[2];
@@ -734,7 +734,7 @@ RT_DEV bool beam_meets_leaf(const DScene& S, const TraceStack& st, uint32_t firs
     const f3 n = mk3(b.z, b.w, c.x);
     const f3 rel = mk3(p.x - a.x, p.y - a.y, p.z - a.z);
     const float nob = dotf(n, rel), nD = dotf(n, D);
-    const float n1 = R * ((fabsf(n.x) + fabsf(n.y)) + fabsf(n.z));
+    const float n1 = R * 1.00001f;  // the jittered light positions lie in the BALL of radius 0.25 < R (light.go:94), so |n . j| <= R |n|_2, and |n|_2 <= 1 + 2^-22
     const float s_a = lo * (1.0f - 64.0f * kSlabMargin), s_b = hi * (1.0f + 64.0f * kSlabMargin);  // lo >= s0 > 0
     const float vlo = fminf(fmaf(s_a, nD - n1, nob), fmaf(s_b, nD - n1, nob)), vhi = fmaxf(fmaf(s_a, nD + n1, nob), fmaf(s_b, nD + n1, nob));
     const float m = kSlabMargin * (((fabsf(rel.x) + fabsf(rel.y)) + fabsf(rel.z)) + s_b * (((fabsf(D.x) + fabsf(D.y)) + fabsf(D.z)) + 3.0f * R));

@@ -1255,7 +1255,7 @@ extern "C" int sim_ball_beam_slab(const orc_scene* s, const rt_image_spec* spec,
                                 const Slab& sl = slab_of(e);
                                 if (!sl.any) { clear = false; continue; }
                                 const double np_ = sl.n[0] * p[0] + sl.n[1] * p[1] + sl.n[2] * p[2], nD = sl.n[0] * D[0] + sl.n[1] * D[1] + sl.n[2] * D[2];
-                                const double n1 = R * (std::fabs(sl.n[0]) + std::fabs(sl.n[1]) + std::fabs(sl.n[2]));
+                                const double n1 = std::getenv("SIM_L1") ? R * (std::fabs(sl.n[0]) + std::fabs(sl.n[1]) + std::fabs(sl.n[2])) : R * 1.00001;  // the jittered light positions lie in the BALL of radius R: |n . j| <= R |n|_2
                                 const double lo = std::min(np_ + a * (nD - n1), np_ + b * (nD - n1)), hi = std::max(np_ + a * (nD + n1), np_ + b * (nD + n1));
                                 if (hi < sl.dmin || lo > sl.dmax) continue;  // the beam misses the slab inside the box
                                 clear = false;
