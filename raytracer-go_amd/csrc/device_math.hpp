@@ -84,6 +84,7 @@ constexpr uint32_t kLeaf = 0x80000000u;   // ChildRecord.w1
 constexpr uint32_t kPrimTriangle = 1u;    // prims[3i+2].y bits: bit0 triangle, bit1 single sided, material << 2
 constexpr uint32_t kPrimSingleSided = 2u;
 
+constexpr int kLeafBoundQuads = 4;
 struct DScene {
     const float4* recs;    // 2 float4 per child record: {min.xyz, max.x}, {max.y, max.z, w0, w1}
     const uint4* qblocks;  // 5 uint4 per block: the same tree with quantised boxes (octree.hpp QBlock), shadow rays only
@@ -92,8 +93,8 @@ struct DScene {
     const int* prim_ids;   // leaf-order shape q -> position in Scene.Shapes
     const uint32_t* block_first;     // per block (qblocks): its first child record (recs)
     const float4* block_box;         // 2 float4 per block: {min.xyz, -}, {max.xyz, -} of its children's boxes
-    const float4* leaf_bound;        // 3 float4 per SHAPE index, filled at every leaf's FIRST shape (k_leaf_bounds): the leaf's exact
-                                     // box and its slab {min.xyz, max.x} {max.yz, n.xy} {n.z, dmin, dmax, -}; nullptr: no slabs
+    const float4* leaf_bound;        // kLeafBoundQuads float4 per SHAPE index, filled at every leaf's FIRST shape (k_leaf_bounds): the leaf's
+                                     // exact box and its two slabs {min.xyz, max.x} {max.yz, n.xy} {n.z, dmin, dmax, n2.x} {n2.yz, d2min, d2max}; nullptr: none
     const DMaterial* materials;
     const DTexture* textures;
     const DLight* lights;
@@ -414,7 +415,9 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
 // met 4.5 leaf boxes and tested 19.5 shapes, an unoccluded one 1.0 and 4.9 (scripts/sim_leaf_slab.py).  Every leaf
 // therefore has a second bound, two parallel planes around its shapes, {x : dmin <= n . (x - box.min) <= dmax} with n
 // the leaf's mean triangle normal (DScene::leaf_bound, made on the device by k_leaf_bounds): a ray can only hit a
-// shape of the leaf where it is inside the leaf's box AND between the planes.  With it the same rays test 7.2 and
+// shape of the leaf where it is inside the leaf's box AND between the planes; a second pair of planes, normal to the
+// in-plane direction in which the leaf is narrowest, bounds the leaf inside the first (a third fewer shape tests again).
+// With the first slab the same rays test 7.2 and
 // 0.1 shapes, and a pair's beam (below) that meets a leaf's box but not its slab there goes on: 64 % instead of 53 %
 // of the shadow rays belong to pairs that a beam proves clear.  The tests only ever say "cannot hit" with margins
 // (2^-16 of the distances involved, against float32 rounding of 2^-23 in the shape tests), so the answers are the
@@ -422,7 +425,7 @@ RT_DEV bool traverse(const DScene& S, const TraceStack& st, f3 o, f3 d, float tm
 constexpr float kSlabMargin = 1.52587890625e-05f;  // 2^-16
 // true: the ray cannot hit a shape of the leaf.  Box interval in local coordinates ((plane - o) * inv: a rounding
 // error relative to the distance, not to |o|), never used to cull by itself; the slab is evaluated at its two ends.
-RT_DEV bool ray_misses_leaf_slab(const float4 b0, const float4 b1, const float4 b2, f3 o, f3 d, f3 inv, float tmin, float tmax) {
+RT_DEV bool ray_misses_leaf_slab(const float4 b0, const float4 b1, const float4 b2, const float4 b3, f3 o, f3 d, f3 inv, float tmin, float tmax) {
     const float x0 = (b0.x - o.x) * inv.x, x1 = (b0.w - o.x) * inv.x;
     const float y0 = (b0.y - o.y) * inv.y, y1 = (b1.x - o.y) * inv.y;
     const float z0 = (b0.z - o.z) * inv.z, z1 = (b1.y - o.z) * inv.z;
@@ -436,7 +439,18 @@ RT_DEV bool ray_misses_leaf_slab(const float4 b0, const float4 b1, const float4 
     const float a0 = fmaf(tn, nd, nob), a1 = fmaf(tf, nd, nob);
     const float m = kSlabMargin * ((fabsf(rel.x) + fabsf(rel.y)) + fabsf(rel.z));  // |n| <= 1: the size of the terms that cancel
     // (comparisons with a NaN are false: such a leaf is kept)
-    return fmaxf(a0, a1) + m < b2.y || fminf(a0, a1) - m > b2.z;
+    if (fmaxf(a0, a1) + m < b2.y || fminf(a0, a1) - m > b2.z) return true;
+    // The second slab, along the in-plane direction n2 in which the leaf is narrowest, over the piece of [tn, tf] on
+    // which the ray is between the first slab's (widened) planes: t = (plane - n . rel) / (n . d); a NaN or an infinity
+    // from n . d = 0 leaves [tn, tf] as it is or empties it, and an emptied piece only makes the test below vacuous.
+    const float ind = 1.0f / nd;
+    const float ta = ((b2.y - m) - nob) * ind, tb = ((b2.z + m) - nob) * ind;
+    const float sn0 = fmaxf(tn, fminf(ta, tb)), sf0 = fminf(tf, fmaxf(ta, tb));
+    const float sn = fmaf(-4.0f * kSlabMargin, fabsf(sn0), sn0), sf = fmaf(4.0f * kSlabMargin, fabsf(sf0), sf0);
+    const f3 n2 = mk3(b2.w, b3.x, b3.y);
+    const float nob2 = dotf(n2, rel), nd2 = dotf(n2, d);
+    const float c0 = fmaf(sn, nd2, nob2), c1 = fmaf(sf, nd2, nob2);
+    return fmaxf(c0, c1) + m < b3.z || fminf(c0, c1) - m > b3.w;
 }
 
 // ---- one conservative walk for all the shadow rays of a (hit, light) pair ------------------------------------
@@ -719,8 +733,8 @@ static_assert(kPendCap >= 6, "beam_store_origin() uses six of the leaf-queue wor
 // range of n . (x - box.min) over the beam's points misses [dmin, dmax]: at parameter s that range is
 // n . (p - box.min) + s (n . D -/+ R |n|_2), linear in s, so the two ends of [lo, hi] bound it.
 RT_DEV bool beam_meets_leaf(const DScene& S, const TraceStack& st, uint32_t first_shape, const Beam& bm, float R) {
-    const float4* const lb = S.leaf_bound + 3 * (size_t)first_shape;
-    const float4 a = lb[0], b = lb[1], c = lb[2];
+    const float4* const lb = S.leaf_bound + kLeafBoundQuads * (size_t)first_shape;
+    const float4 a = lb[0], b = lb[1], c = lb[2], e = lb[3];
     const uint32_t* const w = st.lds + kLdsStackDepth * st.lds_stride;
     const f3 p = mk3(__uint_as_float(w[0]), __uint_as_float(w[st.lds_stride]), __uint_as_float(w[2 * st.lds_stride]));
     const f3 D = mk3(__uint_as_float(w[3 * st.lds_stride]), __uint_as_float(w[4 * st.lds_stride]), __uint_as_float(w[5 * st.lds_stride]));
@@ -738,7 +752,12 @@ RT_DEV bool beam_meets_leaf(const DScene& S, const TraceStack& st, uint32_t firs
     const float s_a = lo * (1.0f - 64.0f * kSlabMargin), s_b = hi * (1.0f + 64.0f * kSlabMargin);  // lo >= s0 > 0
     const float vlo = fminf(fmaf(s_a, nD - n1, nob), fmaf(s_b, nD - n1, nob)), vhi = fmaxf(fmaf(s_a, nD + n1, nob), fmaf(s_b, nD + n1, nob));
     const float m = kSlabMargin * (((fabsf(rel.x) + fabsf(rel.y)) + fabsf(rel.z)) + s_b * (((fabsf(D.x) + fabsf(D.y)) + fabsf(D.z)) + 3.0f * R));
-    return !(vhi + m < c.y || vlo - m > c.z);
+    if (vhi + m < c.y || vlo - m > c.z) return false;
+    // the second slab (the in-plane direction n2 in which the leaf is narrowest), over the same [lo, hi]
+    const f3 n2 = mk3(c.w, e.x, e.y);
+    const float nob2 = dotf(n2, rel), nD2 = dotf(n2, D);
+    const float wlo = fminf(fmaf(s_a, nD2 - n1, nob2), fmaf(s_b, nD2 - n1, nob2)), whi = fmaxf(fmaf(s_a, nD2 + n1, nob2), fmaf(s_b, nD2 + n1, nob2));
+    return !(whi + m < e.z || wlo - m > e.w);
 }
 RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, const Beam& bm, float R, uint32_t* cur_out, int* sp_out) {
     uint32_t cur = 0u;  // block index; the root is block 0
@@ -925,9 +944,9 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
                     RT_PROF_POINT(3);  // leaf slab tests
                     uint32_t* const slot = oq + (item - first_excl) * st.lds_stride;
                     const uint32_t leaf = *slot;
-                    const float4* const lb = S.leaf_bound + 3 * (size_t)(leaf >> 8);
-                    const float4 b0 = lb[0], b1 = lb[1], b2 = lb[2];
-                    if (ray_misses_leaf_slab(b0, b1, b2, oo, dd, ii, tmn, tmx)) *slot = leaf & ~0xffu;
+                    const float4* const lb = S.leaf_bound + kLeafBoundQuads * (size_t)(leaf >> 8);
+                    const float4 b0 = lb[0], b1 = lb[1], b2 = lb[2], b3 = lb[3];
+                    if (ray_misses_leaf_slab(b0, b1, b2, b3, oo, dd, ii, tmn, tmx)) *slot = leaf & ~0xffu;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -590,7 +590,8 @@ __global__ void k_sum_counters(unsigned long long* fc) {
 // Scene set-up: one thread per child record; a leaf's record files the leaf's exact box and its slab under the leaf's
 // first shape (DScene::leaf_bound, device_math.hpp "leaf slabs").  n = the mean of the leaf's triangle normals (each
 // turned to the side of the first), narrowed to float32; dmin / dmax = the range of n . (vertex - box.min) over the
-// leaf's vertices in float64 with that float32 n, widened by 2^-16 of the box's size and rounded outward.  A sphere
+// leaf's vertices in float64 with that float32 n, widened by 2^-16 of the box's size and rounded outward; the same for
+// n2, the one of 16 directions normal to n along which the leaf is narrowest (the second slab).  A sphere
 // of the leaf adds its extent along n (centre -/+ radius) and no normal; a leaf of spheres only, or whose normals cancel,
 // gets n = 0 and [-inf, +inf]: it is never culled.
 __global__ __launch_bounds__(kBlock) void k_leaf_bounds(const float4* recs, const float4* prims, uint32_t n_recs, float4* leaf_bound) {
@@ -633,10 +634,50 @@ __global__ __launch_bounds__(kBlock) void k_leaf_bounds(const float4* recs, cons
         dmin = __double2float_rd(lo - pad);
         dmax = __double2float_ru(hi + pad);
     }
-    float4* out = leaf_bound + 3 * (size_t)first;
+    // the second slab: of 16 directions in the plane normal to n, the one along which the leaf is narrowest
+    float n2f[3] = {0.0f, 0.0f, 0.0f};
+    float d2min = -__builtin_inff(), d2max = __builtin_inff();
+    if (dmax < __builtin_inff()) {
+        const double nn[3] = {(double)nf[0], (double)nf[1], (double)nf[2]};
+        const int ax = fabs(nn[0]) < fabs(nn[1]) ? (fabs(nn[0]) < fabs(nn[2]) ? 0 : 2) : (fabs(nn[1]) < fabs(nn[2]) ? 1 : 2);
+        double e[3] = {0.0, 0.0, 0.0};
+        e[ax] = 1.0;
+        double u[3] = {nn[1] * e[2] - nn[2] * e[1], nn[2] * e[0] - nn[0] * e[2], nn[0] * e[1] - nn[1] * e[0]};
+        const double ul = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        for (int k = 0; k < 3; ++k) u[k] /= ul;  // |n x e| >= sqrt(2/3) |n|: the smallest component of n was crossed out
+        const double v[3] = {nn[1] * u[2] - nn[2] * u[1], nn[2] * u[0] - nn[0] * u[2], nn[0] * u[1] - nn[1] * u[0]};
+        double best = 1e300;
+        for (int q = 0; q < 16; ++q) {
+            const double c = cos(q * (M_PI / 16.0)), sn = sin(q * (M_PI / 16.0));
+            const float df[3] = {(float)(c * u[0] + sn * v[0]), (float)(c * u[1] + sn * v[1]), (float)(c * u[2] + sn * v[2])};
+            double lo = 1e300, hi = -1e300;
+            for (uint32_t k = 0; k < count; ++k) {
+                const float4 p0 = prims[3 * (size_t)(first + k)], p1 = prims[3 * (size_t)(first + k) + 1], p2 = prims[3 * (size_t)(first + k) + 2];
+                if (!(__float_as_uint(p2.y) & kPrimTriangle)) {
+                    const double t = ((double)df[0] * ((double)p0.x - (double)a.x) + (double)df[1] * ((double)p0.y - (double)a.y)) + (double)df[2] * ((double)p0.z - (double)a.z);
+                    const double r = fabs((double)p0.w) * 1.000001;
+                    lo = t - r < lo ? t - r : lo; hi = t + r > hi ? t + r : hi;
+                    continue;
+                }
+                const double vx[3][3] = {{p0.x, p0.y, p0.z}, {p0.w, p1.x, p1.y}, {p1.z, p1.w, p2.x}};
+                for (int w = 0; w < 3; ++w) {
+                    const double t = ((double)df[0] * (vx[w][0] - (double)a.x) + (double)df[1] * (vx[w][1] - (double)a.y)) + (double)df[2] * (vx[w][2] - (double)a.z);
+                    lo = t < lo ? t : lo; hi = t > hi ? t : hi;
+                }
+            }
+            if (hi - lo < best) {
+                best = hi - lo;
+                const double pad = 1.52587890625e-05 * ((((double)a.w - a.x) + ((double)b.x - a.y)) + ((double)b.y - a.z)) + 1e-30;
+                n2f[0] = df[0]; n2f[1] = df[1]; n2f[2] = df[2];
+                d2min = __double2float_rd(lo - pad); d2max = __double2float_ru(hi + pad);
+            }
+        }
+    }
+    float4* out = leaf_bound + kLeafBoundQuads * (size_t)first;
     out[0] = a;
     out[1] = make_float4(b.x, b.y, nf[0], nf[1]);
-    out[2] = make_float4(nf[2], dmin, dmax, 0.0f);
+    out[2] = make_float4(nf[2], dmin, dmax, n2f[0]);
+    out[3] = make_float4(n2f[1], n2f[2], d2min, d2max);
 }
 
 // One lane per (PhongBlinn hit, positional light, repetition lane).  group = lanes per (hit, light):
@@ -1503,7 +1544,7 @@ static int finish_scene(const rt_scene_desc* desc, const HostScene& h, rt_scene*
     // (RTGO_SLAB=0: none, an A/B switch).  Unfiled entries are never read; the kernel runs on the null stream, before any render.
     const char* slab_env = std::getenv("RTGO_SLAB");
     const bool slabs = RTGO_LEAF_SLAB && !(slab_env && std::strcmp(slab_env, "0") == 0) && !h.flat.records.empty();
-    const size_t leaf_bound_bytes = slabs ? h.prim_words * sizeof(float) : 0;
+    const size_t leaf_bound_bytes = slabs ? ((size_t)desc->n_shapes + 1) * kLeafBoundQuads * sizeof(float4) : 0;
     if (slabs) {
         HIP_TRY_S(hipMalloc(&s->d_leaf_bound, leaf_bound_bytes));
         const uint32_t n_recs = (uint32_t)h.flat.records.size();

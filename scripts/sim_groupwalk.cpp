@@ -999,7 +999,7 @@ extern "C" int sim_leaf_slab(const orc_scene* s, const rt_image_spec* spec, uint
     Node* root = effective(sc.wide_root);
     for (int i = 0; i < 16; ++i) out[i] = 0;
     if (root->as_leaf) return 0;
-    struct Slab { double n[3], dmin, dmax; bool any; };
+    struct Slab { double n[3], dmin, dmax; bool any; double n2[3], d2min, d2max; };
     std::unordered_map<Node*, Slab> slabs;
     const int inner_max = std::getenv("SIM_INNER_MAX") ? std::atoi(std::getenv("SIM_INNER_MAX")) : 64;  // mode 2: inner children with at most this many shapes get a slab too
     static const double dirs[10][3] = {{1, 1, 1}, {1, 1, -1}, {1, -1, 1}, {1, -1, -1}, {1, 1, 0}, {1, -1, 0}, {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1}};
@@ -1040,6 +1040,22 @@ extern "C" int sim_leaf_slab(const orc_scene* s, const rt_image_spec* spec, uint
             }
             const double pad = 1e-5 * (std::fabs(sl.dmin) + std::fabs(sl.dmax) + 1e-3);
             sl.dmin -= pad; sl.dmax += pad;
+            if (sl.any && mode == 3) {  // the in-plane direction (of 16) along which the leaf is narrowest
+                double u[3] = {0, 0, 0};
+                const int ax = std::fabs(sl.n[0]) < std::fabs(sl.n[1]) ? (std::fabs(sl.n[0]) < std::fabs(sl.n[2]) ? 0 : 2) : (std::fabs(sl.n[1]) < std::fabs(sl.n[2]) ? 1 : 2);
+                double e[3] = {0, 0, 0}; e[ax] = 1;
+                u[0] = sl.n[1] * e[2] - sl.n[2] * e[1]; u[1] = sl.n[2] * e[0] - sl.n[0] * e[2]; u[2] = sl.n[0] * e[1] - sl.n[1] * e[0];
+                const double ul = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+                for (int k = 0; k < 3; ++k) u[k] /= ul;
+                const double v[3] = {sl.n[1] * u[2] - sl.n[2] * u[1], sl.n[2] * u[0] - sl.n[0] * u[2], sl.n[0] * u[1] - sl.n[1] * u[0]};
+                double best = 1e300;
+                for (int q = 0; q < 16; ++q) {
+                    const double c = std::cos(q * M_PI / 16), s_ = std::sin(q * M_PI / 16);
+                    const double d[3] = {c * u[0] + s_ * v[0], c * u[1] + s_ * v[1], c * u[2] + s_ * v[2]};
+                    double lo, hi; span(d, &lo, &hi);
+                    if (hi - lo < best) { best = hi - lo; for (int k = 0; k < 3; ++k) sl.n2[k] = d[k]; sl.d2min = lo - pad; sl.d2max = hi + pad; }
+                }
+            }
         }
         return slabs.emplace(lf, sl).first->second;
     };
@@ -1082,6 +1098,14 @@ extern "C" int sim_leaf_slab(const orc_scene* s, const rt_image_spec* spec, uint
                             const double a0 = so + (double)tn * sd, a1 = so + (double)tf * sd;
                             const double m = 1e-5 * (std::fabs(a0) + std::fabs(a1));
                             if (std::max(a0, a1) + m < sl.dmin || std::min(a0, a1) - m > sl.dmax) continue;
+                            if (mode == 3) {
+                                // inside the first slab the ray runs from t0s to t1s; the second slab over that piece
+                                double t0s = tn, t1s = tf;
+                                if (sd != 0 && !std::getenv("SIM_NOCLIP")) { const double ta = (sl.dmin - so) / sd, tb = (sl.dmax - so) / sd; t0s = std::max(t0s, std::min(ta, tb)); t1s = std::min(t1s, std::max(ta, tb)); }
+                                const double so2 = sl.n2[0] * r.p.x + sl.n2[1] * r.p.y + sl.n2[2] * r.p.z, sd2 = sl.n2[0] * r.d.x + sl.n2[1] * r.d.y + sl.n2[2] * r.d.z;
+                                const double b0 = so2 + t0s * sd2, b1 = so2 + t1s * sd2;
+                                if (std::max(b0, b1) + m < sl.d2min || std::min(b0, b1) - m > sl.d2max) continue;
+                            }
                         }
                     }
                     c[2] += 1;

@@ -13,9 +13,9 @@ L.sim_leaf_slab.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_voi
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 spec, scene = (scenes.config3 if cfg == 3 else scenes.config5)(200, 112, 1, 16)
 flat = abi.FlatScene(scene)
-h = L.orc_scene_create(C.addressof(flat.desc)); L.orc_set_tree(h, 1); L.orc_set_leaf_size(h, 6)
+h = L.orc_scene_create(C.addressof(flat.desc)); L.orc_set_tree(h, 1); L.orc_set_leaf_size(h, int(os.environ.get('SIM_LEAF', '20')))
 s = abi.image_spec(spec)
-for mode, name in enumerate(["mean normal", "best of 10 diagonals", "mean normal, inner too"]):
+for mode, name in enumerate(["mean normal", "best of 10 diagonals", "mean normal, inner too", "mean normal + narrowest in-plane direction"]):
     o = np.zeros(16)
     L.sim_leaf_slab(h, C.addressof(s), 0x5EED, mode, o.ctypes.data)
     for cls, b in (("occluded", 0), ("others", 6)):
