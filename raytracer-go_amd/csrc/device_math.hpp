@@ -236,6 +236,9 @@ constexpr int kLdsStackDepth = RTGO_LDS_STACK;
 #ifndef RTGO_BEAM_CAP
 #define RTGO_BEAM_CAP 32  // beam_is_clear(): block visits after which a beam's walk gives up (0: never).  With leaf slabs a walk no longer stops at the first leaf BOX it meets, and the longest of a wavefront's 64 walks sets its pace: frame 231.5 ms without a cap, 237.3 / 232.6 / 228.8 / 228.9 with 12 / 16 / 24 / 32 (k_pair_beam alone 28.9 -> 17 ms; 0.5 % fewer rays decided by beams at 32)
 #endif
+#ifndef RTGO_BEAM_SLAB2
+#define RTGO_BEAM_SLAB2 1
+#endif
 #ifndef RTGO_LEAF_SLAB
 #define RTGO_LEAF_SLAB 1  // occluded(), beam_is_clear(): leaves have a slab besides their box (0: A/B switch)
 #endif
@@ -753,6 +756,10 @@ RT_DEV bool beam_meets_leaf(const DScene& S, const TraceStack& st, uint32_t firs
     const float vlo = fminf(fmaf(s_a, nD - n1, nob), fmaf(s_b, nD - n1, nob)), vhi = fmaxf(fmaf(s_a, nD + n1, nob), fmaf(s_b, nD + n1, nob));
     const float m = kSlabMargin * (((fabsf(rel.x) + fabsf(rel.y)) + fabsf(rel.z)) + s_b * (((fabsf(D.x) + fabsf(D.y)) + fabsf(D.z)) + 3.0f * R));
     if (vhi + m < c.y || vlo - m > c.z) return false;
+#if !RTGO_BEAM_SLAB2
+    (void)e;
+    return true;
+#endif
     // the second slab (the in-plane direction n2 in which the leaf is narrowest), over the same [lo, hi]
     const f3 n2 = mk3(c.w, e.x, e.y);
     const float nob2 = dotf(n2, rel), nD2 = dotf(n2, D);
