@@ -723,6 +723,7 @@ RT_DEV bool beam_meets_record(const DScene& S, uint32_t rec, const Beam& bm, uin
 constexpr int kResumeWords = 12;
 constexpr int kResumeStack = kLdsStackDepth < kResumeWords - 1 ? kLdsStackDepth : kResumeWords - 1;  // entries handed over at most
 constexpr uint32_t kResumeRoot = 0xffffffffu;
+constexpr uint32_t kResumeClear = 0xfffffffeu;  // the beam met no leaf: every ray of the pair is unoccluded, only the spot cone is left to test per ray
 // The pair's point p and D = light - p wait in the lane's leaf-queue words of LDS (the beam walk queues no leaves), for
 // the few leaves whose box the beam meets: kept in registers through the walk they would be spilled.
 RT_DEV void beam_store_origin(const TraceStack& st, f3 p, f3 D) {

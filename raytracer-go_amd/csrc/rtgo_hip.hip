@@ -537,7 +537,7 @@ __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S,
         const uint32_t i = (it0 + k) * gstride + gtid;
         const bool live = i < n_pairs;
         uint32_t hl = 0, lp = 0, hit_i = 0;
-        bool judge = false;
+        bool judge = false, inside = false;
         Beam bm{};
         if (live) {
             hl = Wk.pairs[i];
@@ -547,7 +547,11 @@ __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S,
             const float4 ro = Wk.ray_o[slot], rdv = Wk.ray_d[slot];
             const f3 p = add3(mk3(ro.x, ro.y, ro.z), scale3(ro.w, mk3(rdv.x, rdv.y, rdv.z)));
             const DLight& L = S.pos_lights[lp];
-            judge = surely_inside_cone(L, p);
+            // A pair that is not inside the spot cone for EVERY jittered light position (one in five of the queued pairs
+            // at config 3: a band of asin(0.25 / distance) either side of the cone's edge) has a beam all the same: a
+            // clear beam leaves its rays only the cone test, which they take in k_shadow without a walk (kResumeClear).
+            inside = surely_inside_cone(L, p);
+            judge = inside || Wk.beam_state != nullptr;
             if (judge) {
                 bm = make_beam(p, ld3(L.pos), kBeamR, 0.01f);
                 beam_store_origin(st, p, sub3(ld3(L.pos), p));
@@ -555,7 +559,8 @@ __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S,
         }
         uint32_t stop_block = 0;
         int stop_sp = 0;
-        const bool clear = beam_is_clear(S, st, judge, bm, kBeamR, &stop_block, &stop_sp) && judge;
+        const bool beam_clear = beam_is_clear(S, st, judge, bm, kBeamR, &stop_block, &stop_sp) && judge;
+        const bool clear = beam_clear && inside;
         if (clear) {
             Wk.vis[(size_t)hit_i * S.n_pos_lights + lp] = (uint32_t)B.reps;
             decided += (unsigned long long)B.reps;
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S,
             keep_bits |= 1u << k;
             if (Wk.beam_state) {  // the walk's stack is still in place (LDS + spill region) until the next round
                 uint32_t* dst = Wk.beam_state + ((size_t)hit_i * S.n_pos_lights + lp) * kResumeWords;
-                if (judge) write_resume(st, stop_block, stop_sp, dst); else dst[0] = kResumeRoot;
+                if (beam_clear) dst[0] = kResumeClear; else if (judge) write_resume(st, stop_block, stop_sp, dst); else dst[0] = kResumeRoot;
             }
         }
       }
@@ -705,7 +710,7 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
     const uint32_t r = gtid & (uint32_t)(group - 1);  // the same in every round: the stride is a multiple of the group
     const unsigned long long low_mask = group == 64 ? ~0ull : ((1ull << group) - 1ull);
     const int lane = (int)__lane_id();
-    unsigned long long launched = 0;  // wave-uniform
+    unsigned long long launched = 0, by_beam = 0;  // wave-uniform: rays walked, rays of pairs whose beam was clear (cone test only)
     const int iters = MANY_REPS ? (B.reps + group - 1) >> group_shift : 1;  // > 1 only when reps > 64
 #ifdef RTGO_PROF
     uint32_t prof_prev_visits = 0, prof_prev_iters = 0;
@@ -718,7 +723,7 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
         for (int itn = 0; itn < iters; ++itn) {
             // every lane of the wavefront runs the same number of rounds so the ballot is convergent
             const uint32_t rep = r + (uint32_t)itn * (uint32_t)group;
-            bool traced = false;
+            bool traced = false, beam_clear = false;
             f3 p = mk3(0.0f, 0.0f, 0.0f), dir = mk3(1.0f, 1.0f, 1.0f);
             float dist = 0.0f;
             const uint32_t* resume = nullptr;  // what the pair's beam walk left (k_pair_beam), filed under (hit, light)
@@ -747,8 +752,11 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
                 // p = L' gives NaN either way), and a dot product with -dir is the negated dot product with dir: one
                 // square root and one division per ray instead of two of each
                 traced = L.kind != RT_LIGHT_SPOT || -dot3(ld3(L.look_dir), dir) >= L.cos_angle;
+                // the pair's beam met no leaf (k_pair_beam, kResumeClear): this ray is unoccluded without a walk
+                if (resume && resume[0] == kResumeClear) { beam_clear = traced; traced = false; }
             }
             launched += (unsigned long long)__popcll(__ballot(traced));
+            by_beam += (unsigned long long)__popcll(__ballot(beam_clear));
             RT_PROF_POINT(2);  // shadow-ray rounds
             // all 64 lanes call: lanes without a ray of their own test shapes for the others
 #ifdef RTGO_PROF
@@ -771,7 +779,7 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
             const bool occ = occluded<true>(S, st, traced, p, dir, 0.01f, dist, resume);
 #endif
             // the visible repetitions of a (hit, light) counted over its lane group: an integer, no summation order
-            const unsigned long long m = __ballot(traced && !occ);
+            const unsigned long long m = __ballot((traced && !occ) || beam_clear);
             count += (uint32_t)__popcll((m >> (lane & ~(group - 1))) & low_mask);
         }
         if (r == 0) {
@@ -788,6 +796,7 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
     }
     // shadow rays actually traced: one 64-bit atomic per wavefront
     if (lane == 0 && launched) atomicAdd(Wk.frame_counters + 2 + (blockIdx.x & (kSubCounters - 1)), launched);
+    if (lane == 0 && by_beam) atomicAdd(Wk.frame_counters + 2 + kSubCounters + (blockIdx.x & (kSubCounters - 1)), by_beam);
 }
 
 
