@@ -23,12 +23,13 @@ quantises: total work is fixed, so "scaling" is "strong".  Two launchers, same p
 At N = 1 the default is the single-device path of the torchrun shape (`--launcher rt_multi` forces the other).
 Fewer visible GPUs than N is an error: a measured line never comes from GPUs that share a device.
 
-value = rays TRAVERSED on the device (closest-hit + any-hit traversals actually launched: primary,
-scattered, and the shadow rays walked through the tree one by one) / wall time of the timed region, scene already
-resident in HBM.  value_rays_decided also counts the shadow rays that were proven unoccluded together with the
-other repetitions of their (hit, light) pair by one conservative beam walk and never generated; rays the reference
-traces but whose outcome cannot matter (zero shading term, outside the spot cone) are in neither.  sec_per_frame
-is the number to compare builds on.  sec_per_frame_one_shot is what the reference's own clock covers
+value = TRAVERSALS launched on the device ("one closest-hit or any-hit traversal actually launched":
+primary and scattered rays, the shadow rays walked through the tree one by one, and the conservative any-hit walks
+of whole (hit, light) pairs, k_pair_beam, one traversal each) / wall time of the timed region, scene already
+resident in HBM.  value_rays_decided counts instead every shadow ray whose visibility the device decided, also the
+ones proven unoccluded together with the other repetitions of their pair by that pair's one beam walk and never
+generated; rays the reference traces but whose outcome cannot matter (zero shading term, outside the spot cone) are in
+neither.  The better the beams, the fewer traversals a frame needs: sec_per_frame is the number to compare builds on.  sec_per_frame_one_shot is what the reference's own clock covers
 (raytracer.go:69-105): tree build + upload + the first frame.
 """
 import argparse
@@ -43,7 +44,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 BOUNDS = os.path.join(ROOT, "profiles", "r03", "bounds.json")  # per-frame counter totals of k_shadow + calibrated unit rates
 KEYS = ("rays", "rays_primary", "rays_continuation", "rays_shadow", "rays_shadow_reference_equivalent",
-        "ms_extend", "ms_shadow", "ms_shade", "ms_render", "rays_shadow_beam", "ms_shadow_busy")
+        "ms_extend", "ms_shadow", "ms_shade", "ms_render", "rays_shadow_beam", "ms_shadow_busy", "beam_walks")
 # in the stats of one rt_multi_render call these are the slowest share's (max), the others are sums over the shares
 MULTI_MAX_KEYS = ("ms_extend", "ms_shadow", "ms_shade", "ms_render")
 
@@ -286,7 +287,7 @@ def main():
                         "room, 4 spot lights + ambient, reps 16, aperture 0.03, depth 16"}
         out = {
             "metric": "Mrays/s (whole node), Stanford Dragon 1080p 64spp" if args.config == 3 else "Mrays/s (whole node), config 5 (Bunny + Dragon + glass, 4K 64spp)",
-            "value": (rays - n_beam) / elapsed / 1e6,
+            "value": (rays - n_beam + tot["beam_walks"]) / elapsed / 1e6,
             "unit": "Mrays/s",
             # + the shadow rays a pair's beam walk proved unoccluded without generating them (rays_per_frame.of_which_decided_by_pair_beams)
             "value_rays_decided": rays / elapsed / 1e6,
@@ -307,6 +308,7 @@ def main():
             "build": build,
             "rays_per_frame": {"primary": tot["rays_primary"] / args.steps, "continuation": tot["rays_continuation"] / args.steps,
                                "shadow": tot["rays_shadow"] / args.steps, "of_which_decided_by_pair_beams": n_beam / args.steps,
+                               "pair_beam_walks": tot["beam_walks"] / args.steps,
                                "shadow_reference_equivalent": tot["rays_shadow_reference_equivalent"] / args.steps},
             "kernel_ms_per_frame_per_gpu": {"k_extend": per_rank("ms_extend"), "k_shadow": per_rank("ms_shadow"),
                                             "k_shadow_busy": per_rank("ms_shadow_busy"), "shade_phong_other": per_rank("ms_shade")},

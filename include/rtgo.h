@@ -148,6 +148,8 @@ typedef struct rt_stats {
     uint64_t rays_shadow_beam;   /* of rays_shadow: decided by a pair's beam walk, never generated as rays */
     double ms_shadow_busy;       /* time during which at least one stream's k_shadow was running (the union of the
                                     launches' intervals; = ms_shadow on one stream), if timed                     */
+    uint64_t beam_walks;         /* conservative any-hit walks launched for whole (hit, light) pairs (k_pair_beam): one
+                                    traversal each, on top of the rays_shadow - rays_shadow_beam rays walked one by one */
 } rt_stats;
 
 typedef struct rt_scene_info {

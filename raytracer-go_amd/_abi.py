@@ -74,7 +74,7 @@ class RtStats(C.Structure):
                 ("phong_hits", C.c_uint64), ("paths", C.c_uint64),
                 ("ms_build", C.c_double), ("ms_render", C.c_double),
                 ("ms_extend", C.c_double), ("ms_shadow", C.c_double), ("ms_shade", C.c_double),
-                ("rays_shadow_beam", C.c_uint64), ("ms_shadow_busy", C.c_double)]
+                ("rays_shadow_beam", C.c_uint64), ("ms_shadow_busy", C.c_double), ("beam_walks", C.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -91,6 +91,7 @@ RT_DEV bool pixel_of(const Batch& B, uint32_t lpl, int* x, int* row) {
 }
 
 constexpr int kSubCounters = 64;
+constexpr int kCounterSums = 3;  // frame_counters[0 .. 3): the sums; then kSubCounters words per sum that the wavefronts add to
 struct Work {
     float4* ray_o;   // {origin.xyz, hit t}
     float4* ray_d;   // {direction.xyz, bits of hit shape index (-1 = miss)}
@@ -106,8 +107,8 @@ struct Work {
     uint32_t* light_count; // [0, L) pairs per positional light, [L, 2L) their exclusive prefix sums, [2L] pairs k_pair_beam passes on
     uint32_t* counters;  // per batch: [0..D] ray-queue sizes per bounce, [D+1..2D] phong-queue sizes,
                          // [2D+4..3D+3] pair-queue sizes per bounce
-    unsigned long long* frame_counters;  // per call: [0] shadow rays traced, [1] shadow rays decided by a pair's beam walk: the sums
-                                         // (k_sum_counters) of [2, 2 + kSubCounters) and of the kSubCounters words after those, to
+    unsigned long long* frame_counters;  // per call: [0] shadow rays traced, [1] shadow rays decided by a pair's beam walk, [2] beam walks: the
+                                         // sums (k_sum_counters) of [3, 3 + kSubCounters) and of the two runs of kSubCounters words after those, to
                                          // which the wavefronts add (one address takes an atomic every 11 ns, 65,536 per launch)
     uint32_t* overflow;  // traversal stack spill
     uint32_t overflow_stride;
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S,
     const uint32_t gstride = gridDim.x * kBlock;
     const TraceStack st{s_stack + threadIdx.x, Wk.overflow + gtid, (uint32_t)kBlock, Wk.overflow_stride, nullptr};
     uint32_t* const out_counter = Wk.light_count + 2 * S.n_pos_lights;
-    unsigned long long decided = 0;
+    unsigned long long decided = 0, walks = 0;  // (walks: wave-uniform)
     const uint32_t rounds = (n_pairs + gstride - 1) / gstride;  // the same for every thread: block_push_qk is a block-wide operation
     // kPerThread rounds, then ONE push per block for all of them (a pair's place in the queue is not needed before:
     // its resume state is filed under (hit, light), not under that place)
@@ -559,6 +560,7 @@ __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S,
         }
         uint32_t stop_block = 0;
         int stop_sp = 0;
+        walks += (unsigned long long)__popcll(__ballot(judge));
         const bool beam_clear = beam_is_clear(S, st, judge, bm, kBeamR, &stop_block, &stop_sp) && judge;
         const bool clear = beam_clear && inside;
         if (clear) {
@@ -583,13 +585,14 @@ __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S,
           if (pred[k]) Wk.pair_seg[at[k][0]] = Wk.pairs[(it0 + (uint32_t)k) * gstride + gtid];
     }
     for (int off = 32; off > 0; off >>= 1) decided += __shfl_down(decided, off);
-    if (__lane_id() == 0 && decided) atomicAdd(Wk.frame_counters + 2 + kSubCounters + (blockIdx.x & (kSubCounters - 1)), decided);
+    if (__lane_id() == 0 && decided) atomicAdd(Wk.frame_counters + kCounterSums + kSubCounters + (blockIdx.x & (kSubCounters - 1)), decided);
+    if (__lane_id() == 0 && walks) atomicAdd(Wk.frame_counters + kCounterSums + 2 * kSubCounters + (blockIdx.x & (kSubCounters - 1)), walks);
 }
-// the call's two totals from the words the wavefronts added to (one wavefront)
+// the call's three totals from the words the wavefronts added to (one wavefront)
 __global__ void k_sum_counters(unsigned long long* fc) {
-    unsigned long long a = fc[2 + threadIdx.x], b = fc[2 + kSubCounters + threadIdx.x];
-    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
-    if (threadIdx.x == 0) { fc[0] = a; fc[1] = b; }
+    unsigned long long a = fc[kCounterSums + threadIdx.x], b = fc[kCounterSums + kSubCounters + threadIdx.x], c = fc[kCounterSums + 2 * kSubCounters + threadIdx.x];
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); }
+    if (threadIdx.x == 0) { fc[0] = a; fc[1] = b; fc[2] = c; }
 }
 
 // Scene set-up: one thread per child record; a leaf's record files the leaf's exact box and its slab under the leaf's
@@ -795,8 +798,8 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
         }
     }
     // shadow rays actually traced: one 64-bit atomic per wavefront
-    if (lane == 0 && launched) atomicAdd(Wk.frame_counters + 2 + (blockIdx.x & (kSubCounters - 1)), launched);
-    if (lane == 0 && by_beam) atomicAdd(Wk.frame_counters + 2 + kSubCounters + (blockIdx.x & (kSubCounters - 1)), by_beam);
+    if (lane == 0 && launched) atomicAdd(Wk.frame_counters + kCounterSums + (blockIdx.x & (kSubCounters - 1)), launched);
+    if (lane == 0 && by_beam) atomicAdd(Wk.frame_counters + kCounterSums + kSubCounters + (blockIdx.x & (kSubCounters - 1)), by_beam);
 }
 
 
@@ -1115,7 +1118,7 @@ size_t carve_work(Work* w, unsigned char* base, int64_t paths, int depth, int lp
     w->pair_seg = (uint32_t*)take(P * L * sizeof(uint32_t));
     w->light_count = (uint32_t*)take((2 * L + 2) * sizeof(uint32_t));
     w->counters = (uint32_t*)take((size_t)(3 * depth + 8) * sizeof(uint32_t));
-    w->frame_counters = (unsigned long long*)take((2 + 2 * kSubCounters) * sizeof(unsigned long long));
+    w->frame_counters = (unsigned long long*)take((kCounterSums + kCounterSums * kSubCounters) * sizeof(unsigned long long));
     w->overflow = (uint32_t*)take((size_t)overflow_entries * sizeof(uint32_t));
     w->beam_state = nullptr;  // a buffer of its own (Lane::beam_state), made by the calls that walk pair beams
     return off;
@@ -1795,7 +1798,7 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
     struct Span { int a, b; int kind; };  // kind 0 = k_extend, 1 = k_shadow
     std::vector<Span> spans;
     if (timed) HIP_TRY(hipEventRecord(ln.ev_frame[0], stream));
-    HIP_TRY(hipMemsetAsync(wk.frame_counters, 0, (2 + 2 * kSubCounters) * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(wk.frame_counters, 0, (kCounterSums + kCounterSums * kSubCounters) * sizeof(unsigned long long), stream));
     const DCamera cam = make_camera(s, W, H);
     for (int s0 = P.sA; s0 < P.sB; s0 += P.ns_max) {
         const int ns = std::min(P.ns_max, P.sB - s0);
@@ -1869,11 +1872,12 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
     if (stats) {
         unsigned long long* fc = reinterpret_cast<unsigned long long*>(ln.h_counters + 2 * ln.h_counter_words);
         hipLaunchKernelGGL(k_sum_counters, dim3(1), dim3(kSubCounters), 0, stream, wk.frame_counters);
-        HIP_TRY(hipMemcpyAsync(fc, wk.frame_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(fc, wk.frame_counters, kCounterSums * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipEventRecord(ln.ev_frame[1], stream));
         HIP_TRY(hipEventSynchronize(ln.ev_frame[1]));
         st.rays_shadow = fc[0] + fc[1];
         st.rays_shadow_beam = fc[1];
+        st.beam_walks = fc[2];
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ln.ev_frame[0], ln.ev_frame[1]));
         st.ms_render = ms;
@@ -1953,7 +1957,7 @@ static int rt_render_accum_device_impl(rt_scene* s, const rt_image_spec* spec, c
         for (int l = 1; l < n_lanes; ++l) {
             const rt_stats& x = part_stats[(size_t)l];
             t.paths += x.paths; t.rays_primary += x.rays_primary; t.rays_continuation += x.rays_continuation;
-            t.rays_shadow += x.rays_shadow; t.rays_shadow_beam += x.rays_shadow_beam; t.rays_shadow_reference_equivalent += x.rays_shadow_reference_equivalent;
+            t.rays_shadow += x.rays_shadow; t.rays_shadow_beam += x.rays_shadow_beam; t.beam_walks += x.beam_walks; t.rays_shadow_reference_equivalent += x.rays_shadow_reference_equivalent;
             t.phong_hits += x.phong_hits;
             t.ms_extend += x.ms_extend; t.ms_shadow += x.ms_shadow; t.ms_shade += x.ms_shade;  // stream time, summed over the lanes
         }
@@ -2289,7 +2293,7 @@ static int rt_multi_render_impl(rt_multi* m, const rt_image_spec* spec, int32_t 
     if (stats) {
         rt_stats t{};
         for (const rt_stats& x : st) {
-            t.rays_primary += x.rays_primary; t.rays_continuation += x.rays_continuation; t.rays_shadow += x.rays_shadow; t.rays_shadow_beam += x.rays_shadow_beam;
+            t.rays_primary += x.rays_primary; t.rays_continuation += x.rays_continuation; t.rays_shadow += x.rays_shadow; t.rays_shadow_beam += x.rays_shadow_beam; t.beam_walks += x.beam_walks;
             t.rays_shadow_reference_equivalent += x.rays_shadow_reference_equivalent; t.phong_hits += x.phong_hits; t.paths += x.paths;
             t.ms_build = std::max(t.ms_build, x.ms_build); t.ms_render = std::max(t.ms_render, x.ms_render); t.ms_shadow_busy += x.ms_shadow_busy;
             t.ms_extend = std::max(t.ms_extend, x.ms_extend); t.ms_shadow = std::max(t.ms_shadow, x.ms_shadow); t.ms_shade = std::max(t.ms_shade, x.ms_shade);

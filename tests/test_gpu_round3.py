@@ -50,10 +50,12 @@ def test_bench_launchers_agree_on_one_gpu():
     assert ja["launcher"] == "single" and jb["launcher"] == "rt_multi" and jb["rccl_ranks"] == 0
     assert ja["rays_per_frame"] == jb["rays_per_frame"]
     assert ja["n_gpus"] == jb["n_gpus"] == 1
-    # value counts traversals launched; the rays a beam walk settled are only in value_rays_decided
+    # value counts traversals launched: rays walked one by one + one per pair-beam walk; the rays a beam
+    # walk settled are only in value_rays_decided
     for j in (ja, jb):
         rp = j["rays_per_frame"]
-        launched = rp["primary"] + rp["continuation"] + rp["shadow"] - rp["of_which_decided_by_pair_beams"]
+        launched = rp["primary"] + rp["continuation"] + rp["shadow"] - rp["of_which_decided_by_pair_beams"] + rp["pair_beam_walks"]
+        assert 0 < rp["pair_beam_walks"] <= rp["shadow"]
         assert abs(j["value"] * 1e6 * j["sec_per_frame"] - launched) <= 1e-6 * launched
         assert j["value_rays_decided"] >= j["value"]
     print("single", ja["ms_per_step"], "rt_multi", jb["ms_per_step"])
