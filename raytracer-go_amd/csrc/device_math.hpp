@@ -95,6 +95,10 @@ struct DScene {
     const float4* block_box;         // 2 float4 per block: {min.xyz, -}, {max.xyz, -} of its children's boxes
     const float4* leaf_bound;        // kLeafBoundQuads float4 per SHAPE index, filled at every leaf's FIRST shape (k_leaf_bounds): the leaf's
                                      // exact box and its two slabs {min.xyz, max.x} {max.yz, n.xy} {n.z, dmin, dmax, n2.x} {n2.yz, d2min, d2max}; nullptr: none
+    const uint8_t* vox;              // per positional light and cell of a grid over the scene's box: 1 = every ray from any point of the
+                                     // cell to any jittered position of the light is unoccluded (k_voxel_beams); nullptr: no grid
+    float vox_min[3], vox_cs, vox_inv_cs;
+    int vox_n[3];
     const DMaterial* materials;
     const DTexture* textures;
     const DLight* lights;
@@ -502,6 +506,40 @@ RT_DEV Beam make_beam(f3 p, f3 light, float R, float tmin) {
     b.s1 = 1.0001f;
     return b;
 }
+// The same for every ray from ANY point of the box [vlo, vhi] to any jittered light position (the voxel beams of
+// k_voxel_beams): at parameter s the beam spans [vlo_a + s (L_a - R - vlo_a), vhi_a + s (L_a + R - vhi_a)] on axis a, so
+// it meets a box's slab iff s c1 <= hi_a - vlo_a and s c2 >= lo_a - vhi_a with c1 = L_a - R - vlo_a, c2 = L_a + R - vhi_a:
+// make_beam's two half-lines with a point of their own each (vlo = vhi = p gives make_beam).  A box wider than 2R can
+// have c1 > 0 > c2: two upper bounds, of which one is kept, and no lower bound.
+RT_DEV Beam make_box_beam(f3 vlo3, f3 vhi3, f3 light, float R, float tmin) {
+    Beam b;
+    const float lo[3] = {vlo3.x, vlo3.y, vlo3.z}, hi[3] = {vhi3.x, vhi3.y, vhi3.z}, Lp[3] = {light.x, light.y, light.z};
+    float in[3], cn[3], jf[3], cf[3], far2 = 0.0f;
+    b.sign = 0u;
+    const float inf = __builtin_inff();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float c1 = (Lp[a] - R) - lo[a], c2 = (Lp[a] + R) - hi[a];
+        if (c1 > 0.0f && c2 > 0.0f) {
+            in[a] = 1.0f / c2; cn[a] = -hi[a] * in[a]; jf[a] = 1.0f / c1; cf[a] = -lo[a] * jf[a];
+        } else if (c1 < 0.0f && c2 < 0.0f) {
+            in[a] = 1.0f / c1; cn[a] = -lo[a] * in[a]; jf[a] = 1.0f / c2; cf[a] = -hi[a] * jf[a];
+            b.sign |= 1u << a;
+        } else if (c1 <= 0.0f && c2 >= 0.0f) {
+            if (Lp[a] - 0.5f * (lo[a] + hi[a]) < 0.0f) { in[a] = 1.0f / c1; cn[a] = -lo[a] * in[a]; b.sign |= 1u << a; } else { in[a] = 1.0f / c2; cn[a] = -hi[a] * in[a]; }
+            jf[a] = 0.0f; cf[a] = inf;
+        } else {
+            in[a] = 0.0f; cn[a] = -inf; jf[a] = 1.0f / c1; cf[a] = -lo[a] * jf[a];
+        }
+        const float reach = fmaxf(fabsf(Lp[a] - lo[a]), fabsf(Lp[a] - hi[a])) + R;  // the farthest a ray of the beam goes on this axis
+        far2 += reach * reach;
+    }
+    b.inv_n = mk3(in[0], in[1], in[2]); b.c_n = mk3(cn[0], cn[1], cn[2]);
+    b.inv_f = mk3(jf[0], jf[1], jf[2]); b.c_f = mk3(cf[0], cf[1], cf[2]);
+    b.s0 = 0.999f * tmin / sqrtf(far2);
+    b.s1 = 1.0001f;
+    return b;
+}
 // ---- the shadow-ray walk over quantised blocks ------------------------------------------------
 // k_shadow is bound by the vector-memory path (TA busy 77-90 %, about one L1 access per clock and CU,
 // profiles/r02): a visit of the exact blocks issues 17 loads of 16 bytes per lane.  A shadow ray only asks
@@ -710,6 +748,37 @@ RT_DEV bool beam_meets_record(const DScene& S, uint32_t rec, const Beam& bm, uin
     *lo_out = lo; *hi_out = hi;
     return lo <= hi;
 }
+// ---- voxel beams ----------------------------------------------------------------------------------
+// A grid of cubic cells over the scene's box; per positional light and cell one beam from the WHOLE cell to the light's
+// ball (make_box_beam), walked once per scene (k_voxel_beams): if it meets no leaf, every (hit, light) pair whose point
+// lies in the cell is clear, and k_phong_pairs settles it without a beam walk of its own.  The cell's box as the beam saw
+// it (padded: the point's cell index is rounded) is recomputed at the look-up, and the point must lie inside.
+RT_DEV void vox_cell_box(const DScene& S, int ix, int iy, int iz, f3* lo, f3* hi) {
+    const int i[3] = {ix, iy, iz};
+    float l[3], h[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x0 = fmaf((float)i[a], S.vox_cs, S.vox_min[a]), x1 = fmaf((float)(i[a] + 1), S.vox_cs, S.vox_min[a]);
+        const float pad = S.vox_cs * 9.765625e-4f + fmaxf(fabsf(x0), fabsf(x1)) * 9.5367431640625e-07f;  // 2^-10 of a cell + 2^-20 of the coordinate
+        l[a] = x0 - pad; h[a] = x1 + pad;
+    }
+    *lo = mk3(l[0], l[1], l[2]); *hi = mk3(h[0], h[1], h[2]);
+}
+RT_DEV bool vox_clear(const DScene& S, f3 p, int lp) {
+    if (!S.vox) return false;
+    const float f[3] = {(p.x - S.vox_min[0]) * S.vox_inv_cs, (p.y - S.vox_min[1]) * S.vox_inv_cs, (p.z - S.vox_min[2]) * S.vox_inv_cs};
+    int i[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (!(f[a] > -1.0f && f[a] < 16777216.0f)) return false;  // also NaN
+        const int k = (int)f[a];
+        i[a] = k < 0 ? 0 : (k >= S.vox_n[a] ? S.vox_n[a] - 1 : k);
+    }
+    f3 lo, hi;
+    vox_cell_box(S, i[0], i[1], i[2], &lo, &hi);
+    if (!(p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z && p.z <= hi.z)) return false;
+    return S.vox[(((size_t)lp * S.vox_n[2] + i[2]) * S.vox_n[1] + i[1]) * S.vox_n[0] + i[0]] != 0;
+}
 // true: no leaf box of the tree meets the beam.  Every lane of the wavefront calls it (live = this lane has a beam).
 // The walk goes over the quantised blocks (5 loads per visit); a leaf whose quantised box the beam meets is checked
 // against its exact box (the quantised box of a wall's flat triangle is thick enough to be met by a beam that leaves
@@ -726,22 +795,25 @@ constexpr uint32_t kResumeRoot = 0xffffffffu;
 constexpr uint32_t kResumeClear = 0xfffffffeu;  // the beam met no leaf: every ray of the pair is unoccluded, only the spot cone is left to test per ray
 // The pair's point p and D = light - p wait in the lane's leaf-queue words of LDS (the beam walk queues no leaves), for
 // the few leaves whose box the beam meets: kept in registers through the walk they would be spilled.
-RT_DEV void beam_store_origin(const TraceStack& st, f3 p, f3 D) {
+// (h: half the size of the box the beam starts from, k_voxel_beams; zero for a pair's beam)
+RT_DEV void beam_store_origin(const TraceStack& st, f3 p, f3 D, f3 h = mk3(0.0f, 0.0f, 0.0f)) {
     uint32_t* const w = st.lds + kLdsStackDepth * st.lds_stride;
     w[0] = __float_as_uint(p.x); w[st.lds_stride] = __float_as_uint(p.y); w[2 * st.lds_stride] = __float_as_uint(p.z);
     w[3 * st.lds_stride] = __float_as_uint(D.x); w[4 * st.lds_stride] = __float_as_uint(D.y); w[5 * st.lds_stride] = __float_as_uint(D.z);
+    w[6 * st.lds_stride] = __float_as_uint(h.x); w[7 * st.lds_stride] = __float_as_uint(h.y); w[8 * st.lds_stride] = __float_as_uint(h.z);
 }
-static_assert(kPendCap >= 6, "beam_store_origin() uses six of the leaf-queue words");
+static_assert(kPendCap >= 8, "beam_store_origin() uses nine of the leaf-queue words (kPendCap + 1)");
 // The beam against a leaf's exact box and its slab as filed in DScene::leaf_bound (one fetch).  [lo, hi] = the beam's
 // parameters inside the box; no ray of the beam { p + s (D + j), |j_a| <= R } is between the slab's planes there if the
 // range of n . (x - box.min) over the beam's points misses [dmin, dmax]: at parameter s that range is
 // n . (p - box.min) + s (n . D -/+ R |n|_2), linear in s, so the two ends of [lo, hi] bound it.
 RT_DEV bool beam_meets_leaf(const DScene& S, const TraceStack& st, uint32_t first_shape, const Beam& bm, float R) {
     const float4* const lb = S.leaf_bound + kLeafBoundQuads * (size_t)first_shape;
-    const float4 a = lb[0], b = lb[1], c = lb[2], e = lb[3];
+    const float4 a = lb[0], b = lb[1], c = lb[2], q3 = lb[3];
     const uint32_t* const w = st.lds + kLdsStackDepth * st.lds_stride;
     const f3 p = mk3(__uint_as_float(w[0]), __uint_as_float(w[st.lds_stride]), __uint_as_float(w[2 * st.lds_stride]));
     const f3 D = mk3(__uint_as_float(w[3 * st.lds_stride]), __uint_as_float(w[4 * st.lds_stride]), __uint_as_float(w[5 * st.lds_stride]));
+    const f3 h = mk3(__uint_as_float(w[6 * st.lds_stride]), __uint_as_float(w[7 * st.lds_stride]), __uint_as_float(w[8 * st.lds_stride]));
     const bool nx = (bm.sign & 1u) != 0u, ny = (bm.sign & 2u) != 0u, nz = (bm.sign & 4u) != 0u;
     const float ex = fmaf(nx ? a.w : a.x, bm.inv_n.x, bm.c_n.x), xx = fmaf(nx ? a.x : a.w, bm.inv_f.x, bm.c_f.x);
     const float ey = fmaf(ny ? b.x : a.y, bm.inv_n.y, bm.c_n.y), xy = fmaf(ny ? a.y : b.x, bm.inv_f.y, bm.c_f.y);
@@ -754,18 +826,24 @@ RT_DEV bool beam_meets_leaf(const DScene& S, const TraceStack& st, uint32_t firs
     const float nob = dotf(n, rel), nD = dotf(n, D);
     const float n1 = R * 1.00001f;  // the jittered light positions lie in the BALL of radius 0.25 < R (light.go:94), so |n . j| <= R |n|_2, and |n|_2 <= 1 + 2^-22
     const float s_a = lo * (1.0f - 64.0f * kSlabMargin), s_b = hi * (1.0f + 64.0f * kSlabMargin);  // lo >= s0 > 0
-    const float vlo = fminf(fmaf(s_a, nD - n1, nob), fmaf(s_b, nD - n1, nob)), vhi = fmaxf(fmaf(s_a, nD + n1, nob), fmaf(s_b, nD + n1, nob));
-    const float m = kSlabMargin * (((fabsf(rel.x) + fabsf(rel.y)) + fabsf(rel.z)) + s_b * (((fabsf(D.x) + fabsf(D.y)) + fabsf(D.z)) + 3.0f * R));
+    // (a beam that starts from a box: its points at s have n . (x - box.min) within (1 - s) (n . rel -/+ e) + s (n . rel + n . D -/+ n1),
+    // e = the box's half extent along n)
+    const float e1 = (fabsf(n.x) * h.x + fabsf(n.y) * h.y) + fabsf(n.z) * h.z;
+    const float vlo = fminf(fmaf(s_a, (nD - n1) + e1, nob - e1), fmaf(s_b, (nD - n1) + e1, nob - e1));
+    const float vhi = fmaxf(fmaf(s_a, (nD + n1) - e1, nob + e1), fmaf(s_b, (nD + n1) - e1, nob + e1));
+    const float m = kSlabMargin * ((((fabsf(rel.x) + fabsf(rel.y)) + fabsf(rel.z)) + ((h.x + h.y) + h.z)) + s_b * (((fabsf(D.x) + fabsf(D.y)) + fabsf(D.z)) + 3.0f * R));
     if (vhi + m < c.y || vlo - m > c.z) return false;
 #if !RTGO_BEAM_SLAB2
-    (void)e;
+    (void)q3;
     return true;
 #endif
     // the second slab (the in-plane direction n2 in which the leaf is narrowest), over the same [lo, hi]
-    const f3 n2 = mk3(c.w, e.x, e.y);
+    const f3 n2 = mk3(c.w, q3.x, q3.y);
     const float nob2 = dotf(n2, rel), nD2 = dotf(n2, D);
-    const float wlo = fminf(fmaf(s_a, nD2 - n1, nob2), fmaf(s_b, nD2 - n1, nob2)), whi = fmaxf(fmaf(s_a, nD2 + n1, nob2), fmaf(s_b, nD2 + n1, nob2));
-    return !(whi + m < e.z || wlo - m > e.w);
+    const float e2 = (fabsf(n2.x) * h.x + fabsf(n2.y) * h.y) + fabsf(n2.z) * h.z;
+    const float wlo = fminf(fmaf(s_a, (nD2 - n1) + e2, nob2 - e2), fmaf(s_b, (nD2 - n1) + e2, nob2 - e2));
+    const float whi = fmaxf(fmaf(s_a, (nD2 + n1) - e2, nob2 + e2), fmaf(s_b, (nD2 + n1) - e2, nob2 + e2));
+    return !(whi + m < q3.z || wlo - m > q3.w);
 }
 RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, const Beam& bm, float R, uint32_t* cur_out, int* sp_out) {
     uint32_t cur = 0u;  // block index; the root is block 0

@@ -453,7 +453,7 @@ RT_DEV bool surely_inside_cone(const DLight& L, const f3& p) {
 // for every jittered light position.  Only the other pairs are queued for k_shadow, per light
 // (segment l of pair_seg), so that the queue k_pair_compact builds from the segments is light-major.
 // Every pair's visible-repetition count starts at 0 here.
-__global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, const uint32_t* n_hits_ptr) {
+__global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, const uint32_t* n_hits_ptr, uint32_t reps) {
     // kPerThread hits per thread and up to kAtOnce lights per round, then ONE push per block and light
     // (block_push_qk; uniform trip counts: every thread of the block takes part)
     constexpr int kAtOnce = 4;
@@ -461,6 +461,7 @@ __global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, const
     const uint32_t n_hits = *n_hits_ptr;
     const uint32_t first = blockIdx.x * (kBlock * kPerThread);
     if (first >= n_hits) return;
+    unsigned long long decided = 0;  // shadow rays settled by voxel beams
     for (int lp0 = 0; lp0 < S.n_pos_lights; lp0 += kAtOnce) {
         const int n = S.n_pos_lights - lp0 < kAtOnce ? S.n_pos_lights - lp0 : kAtOnce;
 #pragma unroll 1
@@ -472,8 +473,14 @@ __global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, const
                 for (int q = 0; q < n; ++q) {
                     const DLight& L = S.pos_lights[lp0 + q];
                     const f3 comb = phong_term(L, h.m, h.mc, h.p, h.nrm, h.d);
-                    if (!(comb.x == 0.0f && comb.y == 0.0f && comb.z == 0.0f) && !surely_outside_cone(L, h.p)) keep |= 1u << q;
-                    Wk.vis[(size_t)hit_i * S.n_pos_lights + (lp0 + q)] = 0u;
+                    uint32_t v = 0u;
+                    if (!(comb.x == 0.0f && comb.y == 0.0f && comb.z == 0.0f) && !surely_outside_cone(L, h.p)) {
+                        // a pair in a cell whose voxel beam towards this light is clear, and inside the cone for every jittered
+                        // light position, has all its repetitions visible: no beam walk, no rays
+                        if (vox_clear(S, h.p, lp0 + q) && surely_inside_cone(L, h.p)) { v = reps; decided += reps; }
+                        else keep |= 1u << q;
+                    }
+                    Wk.vis[(size_t)hit_i * S.n_pos_lights + (lp0 + q)] = v;
                 }
             }
             s_keep[k][threadIdx.x] = keep;
@@ -490,6 +497,10 @@ __global__ __launch_bounds__(kBlock) void k_phong_pairs(DScene S, Work Wk, const
 #pragma unroll
             for (int q = 0; q < kAtOnce; ++q)
                 if ((pred[k] >> q) & 1u) Wk.pair_seg[(size_t)(lp0 + q) * n_hits + at[k][q]] = first + (uint32_t)k * kBlock + threadIdx.x;
+    }
+    if (S.vox) {  // (wave-uniform: every lane of the block comes here)
+        for (int off = 32; off > 0; off >>= 1) decided += __shfl_down(decided, off);
+        if (__lane_id() == 0 && decided) atomicAdd(Wk.frame_counters + kCounterSums + kSubCounters + (blockIdx.x & (kSubCounters - 1)), decided);
     }
 }
 // exclusive prefix sums of the per-light pair counts; the total is the pair-queue length k_shadow reads
@@ -686,6 +697,38 @@ __global__ __launch_bounds__(kBlock) void k_leaf_bounds(const float4* recs, cons
     out[1] = make_float4(b.x, b.y, nf[0], nf[1]);
     out[2] = make_float4(nf[2], dmin, dmax, n2f[0]);
     out[3] = make_float4(n2f[1], n2f[2], d2min, d2max);
+}
+
+// Scene set-up: one lane per (positional light, cell) of the voxel grid (device_math.hpp "voxel beams"); grid-stride,
+// every lane of a wavefront runs the same number of rounds (beam_is_clear is a wavefront-wide call).
+__global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_voxel_beams(DScene S, uint32_t* overflow, uint32_t overflow_stride, uint8_t* vox, unsigned long long n_cells) {
+    __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
+    const unsigned long long gtid = (unsigned long long)blockIdx.x * kBlock + threadIdx.x, gstride = (unsigned long long)gridDim.x * kBlock;
+    const TraceStack st{s_stack + threadIdx.x, overflow + gtid, (uint32_t)kBlock, overflow_stride, nullptr};
+    const unsigned long long total = n_cells * (unsigned long long)S.n_pos_lights;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < total; base += gstride) {
+        const unsigned long long i = base + threadIdx.x;
+        const bool live = i < total;
+        Beam bm{};
+        if (live) {
+            const int lp = (int)(i / n_cells);
+            unsigned long long c = i - (unsigned long long)lp * n_cells;
+            const int ix = (int)(c % (unsigned long long)S.vox_n[0]); c /= (unsigned long long)S.vox_n[0];
+            const int iy = (int)(c % (unsigned long long)S.vox_n[1]), iz = (int)(c / (unsigned long long)S.vox_n[1]);
+            f3 lo, hi;
+            vox_cell_box(S, ix, iy, iz, &lo, &hi);
+            const f3 L = ld3(S.pos_lights[lp].pos);
+            const f3 ctr = mk3(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z));
+            // (half extents a little over hi - ctr: the centre is rounded)
+            const f3 h = mk3((hi.x - lo.x) * 0.50001f, (hi.y - lo.y) * 0.50001f, (hi.z - lo.z) * 0.50001f);
+            bm = make_box_beam(lo, hi, L, kBeamR, 0.01f);
+            beam_store_origin(st, ctr, sub3(L, ctr), h);
+        }
+        uint32_t stop_block = 0;
+        int stop_sp = 0;
+        const bool clear = beam_is_clear(S, st, live, bm, kBeamR, &stop_block, &stop_sp);
+        if (live) vox[i] = clear ? 1 : 0;
+    }
 }
 
 // One lane per (PhongBlinn hit, positional light, repetition lane).  group = lanes per (hit, light):
@@ -1066,7 +1109,7 @@ constexpr int kLanes = 4;
 struct rt_scene {
     int device = 0;
     DScene d{};
-    void* d_recs = nullptr; void* d_qblocks = nullptr; void* d_prims = nullptr; void* d_tprims = nullptr; void* d_prim_ids = nullptr; void* d_block_first = nullptr; void* d_block_box = nullptr; void* d_leaf_bound = nullptr; void* d_mats = nullptr; void* d_texs = nullptr; void* d_lights = nullptr;
+    void* d_recs = nullptr; void* d_qblocks = nullptr; void* d_prims = nullptr; void* d_tprims = nullptr; void* d_prim_ids = nullptr; void* d_block_first = nullptr; void* d_block_box = nullptr; void* d_leaf_bound = nullptr; void* d_vox = nullptr; void* d_mats = nullptr; void* d_texs = nullptr; void* d_lights = nullptr;
     std::vector<void*> d_tex_pixels;
     rt_scene_info info{};
     double ms_build = 0;
@@ -1573,15 +1616,57 @@ static int finish_scene(const rt_scene_desc* desc, const HostScene& h, rt_scene*
     HIP_TRY_S(hipMemcpy(s->d_lights, h.lights.data(), h.lights.size() * sizeof(DLight), hipMemcpyHostToDevice));
 
     lap("uploads");
-    // traversal stack spill: worst case 7 pending siblings per level, beyond the LDS part
-    const int spill = h.flat.stack_bound + 1 > kLdsStackDepth ? h.flat.stack_bound + 1 - kLdsStackDepth : 0;  // +1: the nearest child is pushed, then popped
-    s->spill = spill;  // the region itself is sized by ensure_overflow() for the grids a call really launches
-
     s->d.recs = (const float4*)s->d_recs; s->d.qblocks = (const uint4*)s->d_qblocks; s->d.prims = (const float4*)s->d_prims; s->d.tprims = (const float4*)s->d_tprims; s->d.prim_ids = (const int*)s->d_prim_ids; s->d.block_first = (const uint32_t*)s->d_block_first; s->d.block_box = (const float4*)s->d_block_box; s->d.leaf_bound = (const float4*)s->d_leaf_bound;
     s->d.materials = (const DMaterial*)s->d_mats; s->d.textures = (const DTexture*)s->d_texs;
     s->d.lights = (const DLight*)s->d_lights;
     s->d.pos_lights = s->d.lights + desc->n_lights + 1;
     s->d.n_lights = (int)desc->n_lights; s->d.n_pos_lights = h.n_pos; s->d.root_ref = h.flat.root_ref;
+    // The voxel beams (device_math.hpp): a grid of at most 128 cubic cells a side over the box of the tree's top block,
+    // one beam per positional light and cell, walked here once.  Only for scenes that get pair beams by default (256
+    // shapes or more), with slabs, and few enough lights for 32 MiB of cells (RTGO_VOXEL=0: none).
+    size_t vox_bytes = 0;
+    {
+        const char* vox_env = std::getenv("RTGO_VOXEL");
+        const bool want = slabs && desc->n_shapes >= 256 && h.n_pos > 0 && !(vox_env && vox_env[0] == '0') && h.flat.block_box.size() >= 8;
+        if (want) {
+            const float* bb = h.flat.block_box.data();  // block 0: {min.xyz, -, max.xyz, -}
+            float ext = 0.0f;
+            for (int a = 0; a < 3; ++a) ext = std::max(ext, bb[4 + a] - bb[a]);
+            int res = 128;
+            if (const char* ev = std::getenv("RTGO_VOXEL_RES")) res = std::max(4, std::min(256, std::atoi(ev)));
+            const float cs = ext / (float)res;
+            unsigned long long n_cells = 1;
+            if (cs > 0.0f && std::isfinite(cs)) {
+                for (int a = 0; a < 3; ++a) {
+                    s->d.vox_min[a] = bb[a];
+                    s->d.vox_n[a] = std::max(1, std::min(res, (int)std::ceil((bb[4 + a] - bb[a]) / cs)));
+                    n_cells *= (unsigned long long)s->d.vox_n[a];
+                }
+                s->d.vox_cs = cs; s->d.vox_inv_cs = 1.0f / cs;
+                const unsigned long long total = n_cells * (unsigned long long)h.n_pos;
+                if (total <= (32ull << 20)) {
+                    vox_bytes = (size_t)total;
+                    HIP_TRY_S(hipMalloc(&s->d_vox, vox_bytes));
+                    const int grid = (int)std::min<unsigned long long>((total + kBlock - 1) / kBlock, 2048ull);
+                    const int spill_v = h.flat.stack_bound + 1 > kLdsStackDepth ? h.flat.stack_bound + 1 - kLdsStackDepth : 0;
+                    const size_t stride = (size_t)grid * kBlock;
+                    void* tmp = nullptr;  // the walks' stack spill region, for this launch only
+                    HIP_TRY_S(hipMalloc(&tmp, std::max<size_t>(1, (size_t)(spill_v + 1) * stride) * sizeof(uint32_t)));
+                    hipLaunchKernelGGL(k_voxel_beams, dim3(grid), dim3(kBlock), 0, 0, s->d, (uint32_t*)tmp, (uint32_t)stride, (uint8_t*)s->d_vox, n_cells);
+                    const hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
+                    (void)hipFree(tmp);
+                    HIP_TRY_S(e1);
+                    HIP_TRY_S(e2);
+                    s->d.vox = (const uint8_t*)s->d_vox;
+                }
+            }
+        }
+    }
+    lap("voxel beams");
+    // traversal stack spill: worst case 7 pending siblings per level, beyond the LDS part
+    const int spill = h.flat.stack_bound + 1 > kLdsStackDepth ? h.flat.stack_bound + 1 - kLdsStackDepth : 0;  // +1: the nearest child is pushed, then popped
+    s->spill = spill;  // the region itself is sized by ensure_overflow() for the grids a call really launches
+
     {  // the lanes' events, streams and pinned counters: made by a thread of their own since the tree build began
         const std::pair<hipError_t, const char*> made = lane_setup->get();
         if (made.first != hipSuccess) return bail(fail(RT_ERR_DEVICE, std::string(made.second) + ": " + hipGetErrorString(made.first)));
@@ -1590,7 +1675,7 @@ static int finish_scene(const rt_scene_desc* desc, const HostScene& h, rt_scene*
     s->info.n_shapes = desc->n_shapes; s->info.n_inner_nodes = h.flat.n_inner;
     s->info.n_child_records = (int64_t)h.flat.records.size();
     s->info.tree_depth = h.flat.depth; s->info.stack_bound = h.flat.stack_bound;
-    s->info.device_bytes = (int64_t)(rec_bytes + h.flat.qblocks.size() * 4 + h.prim_words * 4 + h.prim_words * 4 + leaf_bound_bytes + h.mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
+    s->info.device_bytes = (int64_t)(rec_bytes + h.flat.qblocks.size() * 4 + h.prim_words * 4 + h.prim_words * 4 + leaf_bound_bytes + vox_bytes + h.mats.size() * sizeof(DMaterial) + texs.size() * sizeof(DTexture) +
                                      h.lights.size() * sizeof(DLight)) + tex_bytes;  // + the spill region, see ensure_overflow()
     lap("events");
     return RT_OK;
@@ -1641,7 +1726,7 @@ void rt_scene_destroy(rt_scene* s) {
     }
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
     for (auto& e : s->ev_wall) if (e) (void)hipEventDestroy(e);
-    void* ptrs[] = {s->d_recs, s->d_qblocks, s->d_prims, s->d_tprims, s->d_prim_ids, s->d_block_first, s->d_block_box, s->d_leaf_bound, s->d_mats, s->d_texs, s->d_lights};
+    void* ptrs[] = {s->d_recs, s->d_qblocks, s->d_prims, s->d_tprims, s->d_prim_ids, s->d_block_first, s->d_block_box, s->d_leaf_bound, s->d_vox, s->d_mats, s->d_texs, s->d_lights};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (void* p : s->d_tex_pixels) (void)hipFree(p);
     for (DevBuf* b : {&s->accum, &s->rgba, &s->probe_in, &s->probe_out, &s->probe_out2}) b->release();
@@ -1770,6 +1855,12 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
     }
     const char* beam_env = std::getenv("RTGO_BEAM");
     const bool beams = beam_env ? beam_env[0] != '0' : (s->info.n_shapes >= 256 && reps >= 4);
+    // the voxel beams settle pairs where k_phong_pairs finds them: only with beams on and soft-shadow repetitions to save (RTGO_VOXEL=0: A/B switch)
+    DScene pairs_scene = s->d;
+    {
+        const char* vox_env = std::getenv("RTGO_VOXEL");
+        if (!beams || reps <= 0 || (vox_env && vox_env[0] == '0')) pairs_scene.vox = nullptr;
+    }
     const char* resume_env = std::getenv("RTGO_RESUME");  // "0": rays start at the root, not where their pair's beam stopped (A/B switch)
     const bool resume_on = !(resume_env && resume_env[0] == '0');
     // what a pair's rays resume from: 48 bytes per (path, light) of a batch, in a buffer of the lane's own that only
@@ -1832,7 +1923,7 @@ static int run_render(rt_scene* s, Lane& ln, Arena& arena, const rt_image_spec* 
                     const unsigned long long n_pairs = (unsigned long long)bound * L;
                     uint32_t* pair_counter = wk.counters + 2 * D + 4 + b;
                     HIP_TRY(hipMemsetAsync(wk.light_count, 0, (size_t)L * sizeof(uint32_t), stream));
-                    hipLaunchKernelGGL(k_phong_pairs, dim3((bound + kBlock * kPerThread - 1) / (kBlock * kPerThread)), dim3(kBlock), 0, stream, s->d, wk, n_phong);
+                    hipLaunchKernelGGL(k_phong_pairs, dim3((bound + kBlock * kPerThread - 1) / (kBlock * kPerThread)), dim3(kBlock), 0, stream, pairs_scene, wk, n_phong, (uint32_t)reps);
                     hipLaunchKernelGGL(k_pair_offsets, dim3(1), dim3(64), 0, stream, wk, L, pair_counter);
                     hipLaunchKernelGGL(k_pair_compact, dim3((bound + kBlock - 1) / kBlock, (unsigned)std::min(L, 65535)), dim3(kBlock), 0, stream, wk, n_phong, L);
                     if (reps > 0) {

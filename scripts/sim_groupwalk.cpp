@@ -1305,3 +1305,178 @@ extern "C" int sim_ball_beam_slab(const orc_scene* s, const rt_image_spec* spec,
         }
     return 0;
 }
+
+// ---- sub-leaves: a leaf of up to 31 shapes as groups of G consecutive shapes, each with a box and two slabs of its own ----
+// out (occluded rays / others, stride 8): [0] rays, [1] block visits, [2] leaf boxes met, [3] leaves whose slabs are met,
+// [4] sub-leaves tested, [5] sub-leaves met, [6] shape tests with leaf slabs only, [7] shape tests with sub-leaves; [16] answers changed
+extern "C" int sim_sub_leaf(const orc_scene* s, const rt_image_spec* spec, uint64_t seed, int G, double* out) {
+    const Scene& sc = s->sc;
+    const int W = spec->width, H = spec->height, reps = spec->soft_shadow_monte_carlo_repetitions;
+    const CameraF64 c64 = new_camera(sc, W, H);
+    const Camera<float> cf = narrow_camera<float>(c64);
+    const Tables<float>& T = sc.t32;
+    Node* root = effective(sc.wide_root);
+    for (int i = 0; i < 20; ++i) out[i] = 0;
+    if (root->as_leaf) return 0;
+    struct Bound { double lo[3], hi[3], n[3], dmin, dmax, n2[3], d2min, d2max; bool any; std::vector<int> shapes; };
+    struct LeafB { Bound leaf; std::vector<Bound> subs; };
+    std::unordered_map<Node*, LeafB> cache;
+    auto make_bound = [&](const std::vector<int>& g) {
+        Bound b{};
+        b.shapes = g; b.any = true;
+        for (int k = 0; k < 3; ++k) { b.lo[k] = 1e300; b.hi[k] = -1e300; }
+        std::vector<std::array<double, 3>> pts;
+        double ns[3] = {0, 0, 0};
+        for (int shape : g) {
+            const Shape<float>& sh = T.shapes[(size_t)shape];
+            if (sh.kind != RT_SHAPE_TRIANGLE) { b.any = false; continue; }
+            const double a[3] = {sh.a.x, sh.a.y, sh.a.z}, bb[3] = {sh.b.x, sh.b.y, sh.b.z}, c[3] = {sh.c.x, sh.c.y, sh.c.z};
+            const double e1[3] = {bb[0] - a[0], bb[1] - a[1], bb[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+            double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            if (n[0] * ns[0] + n[1] * ns[1] + n[2] * ns[2] < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+            for (int k = 0; k < 3; ++k) ns[k] += n[k];
+            pts.push_back({a[0], a[1], a[2]}); pts.push_back({bb[0], bb[1], bb[2]}); pts.push_back({c[0], c[1], c[2]});
+        }
+        for (auto& p : pts) for (int k = 0; k < 3; ++k) { b.lo[k] = std::min(b.lo[k], p[k]); b.hi[k] = std::max(b.hi[k], p[k]); }
+        const double len = std::sqrt(ns[0] * ns[0] + ns[1] * ns[1] + ns[2] * ns[2]);
+        if (!b.any || !(len > 0)) { b.any = false; return b; }
+        for (int k = 0; k < 3; ++k) b.n[k] = ns[k] / len;
+        auto span = [&](const double* d, double* lo, double* hi) {
+            *lo = 1e300; *hi = -1e300;
+            for (auto& p : pts) { const double v = d[0] * p[0] + d[1] * p[1] + d[2] * p[2]; *lo = std::min(*lo, v); *hi = std::max(*hi, v); }
+        };
+        span(b.n, &b.dmin, &b.dmax);
+        const int ax = std::fabs(b.n[0]) < std::fabs(b.n[1]) ? (std::fabs(b.n[0]) < std::fabs(b.n[2]) ? 0 : 2) : (std::fabs(b.n[1]) < std::fabs(b.n[2]) ? 1 : 2);
+        double e[3] = {0, 0, 0}; e[ax] = 1;
+        double u[3] = {b.n[1] * e[2] - b.n[2] * e[1], b.n[2] * e[0] - b.n[0] * e[2], b.n[0] * e[1] - b.n[1] * e[0]};
+        const double ul = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        for (int k = 0; k < 3; ++k) u[k] /= ul;
+        const double v[3] = {b.n[1] * u[2] - b.n[2] * u[1], b.n[2] * u[0] - b.n[0] * u[2], b.n[0] * u[1] - b.n[1] * u[0]};
+        double best = 1e300;
+        for (int q = 0; q < 16; ++q) {
+            const double c = std::cos(q * M_PI / 16), s_ = std::sin(q * M_PI / 16);
+            const double d[3] = {c * u[0] + s_ * v[0], c * u[1] + s_ * v[1], c * u[2] + s_ * v[2]};
+            double lo, hi; span(d, &lo, &hi);
+            if (hi - lo < best) { best = hi - lo; for (int k = 0; k < 3; ++k) b.n2[k] = d[k]; b.d2min = lo; b.d2max = hi; }
+        }
+        const double pad = 1.5e-5 * ((b.hi[0] - b.lo[0]) + (b.hi[1] - b.lo[1]) + (b.hi[2] - b.lo[2])) + 1e-12;
+        b.dmin -= pad; b.dmax += pad; b.d2min -= pad; b.d2max += pad;
+        return b;
+    };
+    auto bounds_of = [&](Node* lf) -> const LeafB& {
+        auto it = cache.find(lf);
+        if (it != cache.end()) return it->second;
+        LeafB lb;
+        std::vector<int> g;
+        subtree_shapes(lf, &g);
+        lb.leaf = make_bound(g);
+        for (size_t k = 0; k < g.size(); k += (size_t)G) lb.subs.push_back(make_bound(std::vector<int>(g.begin() + (long)k, g.begin() + (long)std::min(g.size(), k + (size_t)G))));
+        return cache.emplace(lf, std::move(lb)).first->second;
+    };
+    // the device's test: the ray's interval inside the box (never culls by itself), first slab at its ends, second slab on the piece inside the first
+    auto misses = [&](const Bound& b, const Ray<float>& r, double tmin, double tmax, bool own_box) {
+        if (!b.any) return false;
+        double tn = tmin, tf = tmax;
+        if (own_box)
+            for (int a = 0; a < 3; ++a) {
+                const double o = a == 0 ? r.p.x : a == 1 ? r.p.y : r.p.z, d = a == 0 ? r.d.x : a == 1 ? r.d.y : r.d.z;
+                if (d == 0) continue;
+                const double t0 = (b.lo[a] - o) / d, t1 = (b.hi[a] - o) / d;
+                tn = std::max(tn, std::min(t0, t1)); tf = std::min(tf, std::max(t0, t1));
+            }
+        tn -= 6e-5 * std::fabs(tn); tf += 6e-5 * std::fabs(tf);
+        const double so = b.n[0] * r.p.x + b.n[1] * r.p.y + b.n[2] * r.p.z, sd = b.n[0] * r.d.x + b.n[1] * r.d.y + b.n[2] * r.d.z;
+        const double a0 = so + tn * sd, a1 = so + tf * sd, m = 1.5e-5 * (std::fabs(so) + std::fabs(tf * sd));
+        if (std::max(a0, a1) + m < b.dmin || std::min(a0, a1) - m > b.dmax) return true;
+        double t0s = tn, t1s = tf;
+        if (sd != 0) { const double ta = (b.dmin - m - so) / sd, tb = (b.dmax + m - so) / sd; t0s = std::max(t0s, std::min(ta, tb)); t1s = std::min(t1s, std::max(ta, tb)); }
+        const double so2 = b.n2[0] * r.p.x + b.n2[1] * r.p.y + b.n2[2] * r.p.z, sd2 = b.n2[0] * r.d.x + b.n2[1] * r.d.y + b.n2[2] * r.d.z;
+        const double b0 = so2 + t0s * sd2, b1 = so2 + t1s * sd2;
+        return std::max(b0, b1) + m < b.d2min || std::min(b0, b1) - m > b.d2max;
+    };
+    auto walk = [&](const Ray<float>& r, float tmin, float tmax, double* c, bool use_sub) {
+        const StackRay sr = make_stack_ray(r);
+        std::vector<Node*> stack;
+        Node* cur = root;
+        for (;;) {
+            c[0] += 1;
+            Node* pending[8]; int np = 0;
+            for (int k = 0; k < 8; ++k) {
+                Node* e = cur->slot[k ^ sr.sign];
+                if (!e) continue;
+                float tn = tmin, tf = tmax;
+                for (int a = 0; a < 3; ++a) {
+                    const float lo = (sr.sign >> a) & 1 ? e->fmax[a] : e->fmin[a], hi = (sr.sign >> a) & 1 ? e->fmin[a] : e->fmax[a];
+                    const float t0 = lo * sr.inv[a] - sr.oi[a], t1 = hi * sr.inv[a] - sr.oi[a];
+                    if (t0 == t0) tn = std::max(tn, t0);
+                    if (t1 == t1) tf = std::min(tf, t1);
+                }
+                if (!(tn <= tf)) continue;
+                if (e->as_leaf) {
+                    c[1] += 1;
+                    const LeafB& lb = bounds_of(e);
+                    if (misses(lb.leaf, r, tmin, tmax, true)) continue;
+                    c[2] += 1;
+                    bool hit = false;
+                    for (const Bound& sb : lb.subs) {
+                        if (use_sub && lb.subs.size() > 1) {
+                            c[3] += 1;
+                            if (misses(sb, r, tmin, tmax, true)) continue;
+                            c[4] += 1;
+                        }
+                        for (int shape : sb.shapes) {  // (the device tests every shape of every surviving group at once)
+                            c[5] += 1;
+                            const Hit<float> sh = T.shapes[(size_t)shape].kind == RT_SHAPE_TRIANGLE ? triangle_occludes_f32(T.shapes[(size_t)shape], shape, r, tmin, tmax)
+                                                                                                    : shape_hit(T, shape, r, tmin, tmax);
+                            if (sh.t > 0.0f && sh.t <= tmax) hit = true;
+                        }
+                    }
+                    if (hit) return true;
+                    continue;
+                }
+                pending[np++] = e;
+            }
+            for (int i = np - 1; i >= 1; --i) stack.push_back(pending[i]);
+            if (np > 0) { cur = pending[0]; continue; }
+            if (stack.empty()) return false;
+            cur = stack.back();
+            stack.pop_back();
+        }
+    };
+    for (int row = 0; row < H; ++row)
+        for (int i = 0; i < W; ++i) {
+            const RngKey key{(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)(row * W + i), 0u};
+            const Ray<float> r = camera_ray(cf, W, H, i, H - 1 - row, key);
+            Hit<float> hit;
+            if (!trace_stack_f32(sc, r, 0.0f, FLT_MAX, false, hit, nullptr)) continue;
+            const Shape<float>& sh = T.shapes[hit.shape];
+            const Material<float>& m = T.materials[sh.material];
+            if (m.kind != RT_MAT_PHONGBLINN) continue;
+            int lpos = -1;
+            for (size_t li = 0; li < T.lights.size(); ++li) {
+                const Light<float>& L = T.lights[li];
+                if (L.kind == RT_LIGHT_AMBIENT) continue;
+                ++lpos;
+                const V3<float> ldir = unit(sub(L.pos, hit.p));
+                const float inten = saturate(dot(hit.normal, ldir));
+                const V3<float> h = unit(add(ldir, r.d));
+                const float si = std::pow(saturate(dot(hit.normal, h)), m.param);
+                if (inten == 0.0f && (si == 0.0f || (m.spec.x == 0 && m.spec.y == 0 && m.spec.z == 0))) continue;
+                for (int k = 0; k < reps; ++k) {
+                    const V3<float> jit = scale(0.25f, random_in_unit_sphere<float>(key, 0, P_SHADOW, (uint32_t)(lpos * reps + k)));
+                    const V3<float> shifted = add(L.pos, jit);
+                    if (L.kind == RT_LIGHT_SPOT && !(dot(L.look_dir, unit(sub(hit.p, shifted))) >= L.cos_angle)) continue;
+                    const V3<float> ld = sub(shifted, hit.p);
+                    const float d = norm(ld);
+                    const Ray<float> sray{hit.p, scale(1.0f / d, ld)};
+                    double c0[6] = {0, 0, 0, 0, 0, 0}, c1[6] = {0, 0, 0, 0, 0, 0};
+                    const bool oc = walk(sray, 0.01f, d, c0, false);
+                    const bool oc1 = walk(sray, 0.01f, d, c1, true);
+                    if (oc != oc1) out[16] += 1;
+                    double* o = oc ? out : out + 8;
+                    o[0] += 1; o[1] += c1[0]; o[2] += c1[1]; o[3] += c1[2]; o[4] += c1[3]; o[5] += c1[4]; o[6] += c0[5]; o[7] += c1[5];
+                }
+            }
+        }
+    return 0;
+}

@@ -203,7 +203,9 @@ def test_leaf_slabs_change_no_answer(backend, rt, scenes, gold_dir, monkeypatch)
     accumulation buffer and every counter but the beams' share must be identical: on config 3 and config 5 (curved
     meshes, glass, a mirror), and on seeded scenes built to strain the margins — smooth bumpy sheets (thin slabs) seen at
     grazing angles, at the origin and 1000 / 10^4 units away, with spheres, slivers and zero-area triangles among the
-    leaves; explicit any-hit rays (rt_trace_rays) through the big mesh answer alike as well."""
+    leaves; explicit any-hit rays (rt_trace_rays) through the big mesh answer alike as well.  The same scenes with
+    RTGO_VOXEL=0: pairs that their cell's voxel beam (one conservative walk per light and grid cell, at scene creation)
+    would settle get a beam walk of their own instead, and nothing else changes."""
     api = rt
     cases = []
     spec3, scene3 = scenes.config3(240, 135, 4, 16, asset_dir=gold_dir)
@@ -250,6 +252,10 @@ def test_leaf_slabs_change_no_answer(backend, rt, scenes, gold_dir, monkeypatch)
             plain, st1 = dev.render_accum(spec)
             monkeypatch.delenv("RTGO_SLAB")
             slab_only, st2 = dev.render_accum(spec)  # slabs in the rays' shape loop, no beams
+            monkeypatch.setenv("RTGO_BEAM", "1")
+            monkeypatch.setenv("RTGO_VOXEL", "0")
+            no_vox, st3 = dev.render_accum(spec)  # pair beams, but no pair settled by its cell's voxel beam
+            monkeypatch.delenv("RTGO_VOXEL")
             monkeypatch.delenv("RTGO_BEAM")
             if name == "config 3":  # 200,000 explicit any-hit rays through the big mesh, with and without slabs
                 rng = np.random.default_rng(5)
@@ -264,8 +270,13 @@ def test_leaf_slabs_change_no_answer(backend, rt, scenes, gold_dir, monkeypatch)
                 assert np.array_equal(ids_a > 0, ids_b > 0), int(((ids_a > 0) != (ids_b > 0)).sum())
                 assert 0.02 < (ids_a > 0).mean() < 0.98, float((ids_a > 0).mean())
         print(f"{name}: beams decide {st.rays_shadow_beam} of {st.rays_shadow} shadow rays with slabs, {st0.rays_shadow_beam} without")
-        assert np.array_equal(got, want) and np.array_equal(got, plain) and np.array_equal(got, slab_only), \
-            (name, float(np.abs(got - want).max()), float(np.abs(got - plain).max()), float(np.abs(got - slab_only).max()))
+        assert np.array_equal(got, want) and np.array_equal(got, plain) and np.array_equal(got, slab_only) and np.array_equal(got, no_vox), \
+            (name, float(np.abs(got - want).max()), float(np.abs(got - plain).max()), float(np.abs(got - slab_only).max()), float(np.abs(got - no_vox).max()))
         for k in keys:
-            assert getattr(st, k) == getattr(st0, k) == getattr(st1, k) == getattr(st2, k), (name, k)
+            assert getattr(st, k) == getattr(st0, k) == getattr(st1, k) == getattr(st2, k) == getattr(st3, k), (name, k)
+        # the voxel beams settle pairs without a beam walk of their own: fewer walks, the same or more rays decided
+        print(f"{name}: {st.beam_walks} beam walks with the voxel beams, {st3.beam_walks} without")
+        assert st.beam_walks <= st3.beam_walks and st.rays_shadow_beam >= st3.rays_shadow_beam
+        if name in ("config 3", "config 5"):
+            assert st.beam_walks < 0.9 * st3.beam_walks, name
         assert st.rays_shadow_beam >= st0.rays_shadow_beam and st1.rays_shadow_beam == 0 and st2.rays_shadow_beam == 0
