@@ -433,10 +433,14 @@ constexpr float kSlabMargin = 1.52587890625e-05f;  // 2^-16
 // true: the ray cannot hit a shape of the leaf.  Box interval in local coordinates ((plane - o) * inv: a rounding
 // error relative to the distance, not to |o|), never used to cull by itself; the slab is evaluated at its two ends.
 RT_DEV bool ray_misses_leaf_slab(const float4 b0, const float4 b1, const float4 b2, const float4 b3, f3 o, f3 d, f3 inv, float tmin, float tmax) {
+    // With d_a = 0 (1 / d_a an infinity) a plane's distance is an infinity of the right sign — or a NaN beside the other
+    // plane's infinity when the origin lies exactly ON the plane, and fminf / fmaxf would then keep the infinity: a ray
+    // that runs along a face of the leaf's box, where a triangle's edge can lie, would count as outside
+    // (scripts/stress_slabs.py found such rays 10^5 units from the origin, where coordinates are multiples of 2^-7).
+    // So the filed box is 8 ulps of its coordinates larger than the leaf's (k_leaf_bounds): on its own faces no shape lies.
     const float x0 = (b0.x - o.x) * inv.x, x1 = (b0.w - o.x) * inv.x;
     const float y0 = (b0.y - o.y) * inv.y, y1 = (b1.x - o.y) * inv.y;
     const float z0 = (b0.z - o.z) * inv.z, z1 = (b1.y - o.z) * inv.z;
-    // a NaN (0 * inf) drops out of fmaxf / fminf: that axis then bounds nothing
     const float tn0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
     const float tf0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
     const float tn = fmaf(-4.0f * kSlabMargin, fabsf(tn0), tn0), tf = fmaf(4.0f * kSlabMargin, fabsf(tf0), tf0);  // widened, whatever their signs
@@ -448,11 +452,11 @@ RT_DEV bool ray_misses_leaf_slab(const float4 b0, const float4 b1, const float4 
     // (comparisons with a NaN are false: such a leaf is kept)
     if (fmaxf(a0, a1) + m < b2.y || fminf(a0, a1) - m > b2.z) return true;
     // The second slab, along the in-plane direction n2 in which the leaf is narrowest, over the piece of [tn, tf] on
-    // which the ray is between the first slab's (widened) planes: t = (plane - n . rel) / (n . d); a NaN or an infinity
-    // from n . d = 0 leaves [tn, tf] as it is or empties it, and an emptied piece only makes the test below vacuous.
-    const float ind = 1.0f / nd;
+    // which the ray is between the first slab's (widened) planes: t = (plane - n . rel) / (n . d).
+    const float ind = 1.0f / nd;  // (n . d = 0: infinities, or a NaN that fminf / fmaxf drop; a piece that comes out empty decides nothing, below)
     const float ta = ((b2.y - m) - nob) * ind, tb = ((b2.z + m) - nob) * ind;
     const float sn0 = fmaxf(tn, fminf(ta, tb)), sf0 = fminf(tf, fmaxf(ta, tb));
+    if (!(sn0 <= sf0)) return false;  // no piece left, though the first slab is met: rounding at an edge; the second slab then decides nothing
     const float sn = fmaf(-4.0f * kSlabMargin, fabsf(sn0), sn0), sf = fmaf(4.0f * kSlabMargin, fabsf(sf0), sf0);
     const f3 n2 = mk3(b2.w, b3.x, b3.y);
     const float nob2 = dotf(n2, rel), nd2 = dotf(n2, d);
@@ -479,6 +483,22 @@ struct Beam {
     uint32_t sign;              // bit a: the near plane on axis a is the UPPER one
     float s0, s1;
 };
+// A bound is fma(plane, 1 / c, -(P / c)) with P / c rounded BEFORE the subtraction: it errs by up to an ulp of P / c,
+// which far from the origin is more than a leaf is wide in s (scripts/stress_slabs.py: at 10^5 units a beam passed by a
+// box that it met).  Every entry bound is therefore lowered and every exit bound raised by 4 ulps of the largest P / c
+// in use, once per beam: nothing at ordinary distances (10^-6 of the way to the light), a fatter beam far out.
+RT_DEV void beam_slack(float cn[3], float cf[3]) {
+    const float inf = __builtin_inff();
+    float m = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (fabsf(cn[a]) < inf) m = fmaxf(m, fabsf(cn[a]));
+        if (fabsf(cf[a]) < inf) m = fmaxf(m, fabsf(cf[a]));
+    }
+    const float slack = m * 9.5367431640625e-07f;  // 2^-20
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { cn[a] -= slack; cf[a] += slack; }  // (an infinite bound stays what it is; a NaN never bounded anything)
+}
 RT_DEV Beam make_beam(f3 p, f3 light, float R, float tmin) {
     Beam b;
     const float D[3] = {light.x - p.x, light.y - p.y, light.z - p.z}, P[3] = {p.x, p.y, p.z};
@@ -499,6 +519,7 @@ RT_DEV Beam make_beam(f3 p, f3 light, float R, float tmin) {
         }
         cn[a] = -P[a] * in[a];
     }
+    beam_slack(cn, cf);
     b.inv_n = mk3(in[0], in[1], in[2]); b.c_n = mk3(cn[0], cn[1], cn[2]);
     b.inv_f = mk3(jf[0], jf[1], jf[2]); b.c_f = mk3(cf[0], cf[1], cf[2]);
     const float len = sqrtf(D[0] * D[0] + D[1] * D[1] + D[2] * D[2]);
@@ -534,6 +555,7 @@ RT_DEV Beam make_box_beam(f3 vlo3, f3 vhi3, f3 light, float R, float tmin) {
         const float reach = fmaxf(fabsf(Lp[a] - lo[a]), fabsf(Lp[a] - hi[a])) + R;  // the farthest a ray of the beam goes on this axis
         far2 += reach * reach;
     }
+    beam_slack(cn, cf);
     b.inv_n = mk3(in[0], in[1], in[2]); b.c_n = mk3(cn[0], cn[1], cn[2]);
     b.inv_f = mk3(jf[0], jf[1], jf[2]); b.c_f = mk3(cf[0], cf[1], cf[2]);
     b.s0 = 0.999f * tmin / sqrtf(far2);
@@ -818,14 +840,14 @@ RT_DEV bool beam_meets_leaf(const DScene& S, const TraceStack& st, uint32_t firs
     const float ex = fmaf(nx ? a.w : a.x, bm.inv_n.x, bm.c_n.x), xx = fmaf(nx ? a.x : a.w, bm.inv_f.x, bm.c_f.x);
     const float ey = fmaf(ny ? b.x : a.y, bm.inv_n.y, bm.c_n.y), xy = fmaf(ny ? a.y : b.x, bm.inv_f.y, bm.c_f.y);
     const float ez = fmaf(nz ? b.y : a.z, bm.inv_n.z, bm.c_n.z), xz = fmaf(nz ? a.z : b.y, bm.inv_f.z, bm.c_f.z);
-    const float lo = fmaxf(fmaxf(ex, ey), fmaxf(ez, bm.s0));
+    const float lo = fmaxf(fmaxf(ex, ey), fmaxf(ez, bm.s0));  // (widened by the beam's slack already: beam_slack)
     const float hi = fminf(fminf(xx, xy), fminf(xz, bm.s1));
     if (!(lo <= hi)) return false;
     const f3 n = mk3(b.z, b.w, c.x);
     const f3 rel = mk3(p.x - a.x, p.y - a.y, p.z - a.z);
     const float nob = dotf(n, rel), nD = dotf(n, D);
     const float n1 = R * 1.00001f;  // the jittered light positions lie in the BALL of radius 0.25 < R (light.go:94), so |n . j| <= R |n|_2, and |n|_2 <= 1 + 2^-22
-    const float s_a = lo * (1.0f - 64.0f * kSlabMargin), s_b = hi * (1.0f + 64.0f * kSlabMargin);  // lo >= s0 > 0
+    const float s_a = lo - 64.0f * kSlabMargin * fabsf(lo), s_b = hi + 64.0f * kSlabMargin * fabsf(hi);
     // (a beam that starts from a box: its points at s have n . (x - box.min) within (1 - s) (n . rel -/+ e) + s (n . rel + n . D -/+ n1),
     // e = the box's half extent along n)
     const float e1 = (fabsf(n.x) * h.x + fabsf(n.y) * h.y) + fabsf(n.z) * h.z;
@@ -961,6 +983,10 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
             // misses 2.9 of the 8.1, each a block visit that would find nothing).  No branch per entry: every entry is
             // stored at the top, which only moves for the ones that are kept; entries past e[0] test block 0 and are dropped.
             const uint32_t n = e[0] & 0xffu;
+            // fma(box, 1 / d, -(o / d)) is off by up to an ulp of o / d (rounded before the subtraction): far from the origin
+            // that is more than a block is wide.  The walk itself errs the same way with or without a beam; this filter
+            // is an extra test, so it allows for the error (scripts/stress_slabs.py: one ray at 10^5 units lost its occluder).
+            const float slack = 9.5367431640625e-07f * fmaxf(fmaxf(fabsf(r.oi.x), fabsf(r.oi.y)), fabsf(r.oi.z));  // 2^-20 max |o / d|; inf or NaN keeps every block
 #pragma unroll
             for (int k = 0; k < kResumeStack; ++k) {
                 const bool in_use = (uint32_t)k < n;
@@ -974,7 +1000,7 @@ RT_DEV bool occluded(const DScene& S, const TraceStack& st, bool live, f3 o, f3 
                 const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
                 const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
                 st.lds[sp * st.lds_stride] = b;
-                sp += (in_use && tn <= tf) ? 1 : 0;
+                sp += (in_use && !(tn > tf + slack)) ? 1 : 0;
             }
         }
     }

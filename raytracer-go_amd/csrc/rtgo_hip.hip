@@ -616,10 +616,26 @@ __global__ void k_sum_counters(unsigned long long* fc) {
 __global__ __launch_bounds__(kBlock) void k_leaf_bounds(const float4* recs, const float4* prims, uint32_t n_recs, float4* leaf_bound) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n_recs) return;
-    const float4 a = recs[2 * (size_t)i], b = recs[2 * (size_t)i + 1];
-    const uint32_t w0 = __float_as_uint(b.z), w1 = __float_as_uint(b.w);
+    const float4 ra = recs[2 * (size_t)i], rb = recs[2 * (size_t)i + 1];
+    const uint32_t w0 = __float_as_uint(rb.z), w1 = __float_as_uint(rb.w);
     if (!(w1 & kLeafFlag)) return;
     const uint32_t first = w0 >> 8, count = w0 & 0xffu;
+    // The box filed with the slabs must hold the shapes AS THE DEVICE TESTS THEM, in float32.  The record's box holds
+    // the float64 shapes (rounded outward), hence every float32 vertex, but a sphere whose centre was rounded to float32
+    // can stick out of it by half an ulp of the centre (scripts/stress_slabs.py: spheres of radius 0.004 at 10^5 units
+    // from the origin): the box is grown to the float32 spheres' extents.
+    double blo[3] = {(double)ra.x, (double)ra.y, (double)ra.z}, bhi[3] = {(double)ra.w, (double)rb.x, (double)rb.y};
+    for (uint32_t k = 0; k < count; ++k) {
+        const float4 p0 = prims[3 * (size_t)(first + k)], p2 = prims[3 * (size_t)(first + k) + 2];
+        if (__float_as_uint(p2.y) & kPrimTriangle) continue;
+        const double c[3] = {(double)p0.x, (double)p0.y, (double)p0.z}, r = fabs((double)p0.w) * 1.000001;
+        for (int q = 0; q < 3; ++q) { blo[q] = c[q] - r < blo[q] ? c[q] - r : blo[q]; bhi[q] = c[q] + r > bhi[q] ? c[q] + r : bhi[q]; }
+    }
+    // ... and then by 8 ulps of its coordinates, so that a ray origin or a vertex exactly on a face of the leaf's box is strictly
+    // inside the filed one (ray_misses_leaf_slab: a direction component of 0 turns the distance to a plane into 0 or an infinity)
+    for (int q = 0; q < 3; ++q) { blo[q] -= fabs(blo[q]) * 9.5367431640625e-07 + 1e-30; bhi[q] += fabs(bhi[q]) * 9.5367431640625e-07 + 1e-30; }
+    const float4 a = make_float4(__double2float_rd(blo[0]), __double2float_rd(blo[1]), __double2float_rd(blo[2]), __double2float_ru(bhi[0]));
+    const float4 b = make_float4(__double2float_ru(bhi[1]), __double2float_ru(bhi[2]), rb.z, rb.w);
     double ns[3] = {0.0, 0.0, 0.0};
     for (uint32_t k = 0; k < count; ++k) {
         const float4 p0 = prims[3 * (size_t)(first + k)], p1 = prims[3 * (size_t)(first + k) + 1], p2 = prims[3 * (size_t)(first + k) + 2];

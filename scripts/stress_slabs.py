@@ -1,0 +1,96 @@
+"""Stress of the conservative bounds (leaf slabs, pair beams, voxel beams): seeded random scenes rendered with everything
+on and with RTGO_SLAB=0 RTGO_BEAM=0 (every shadow ray walked, every shape of every leaf met tested); the accumulation
+buffers must be bit-identical.  Run on the GPU box: python scripts/stress_slabs.py [scenes]"""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+api = importlib.import_module("raytracer-go_amd")
+backend = importlib.import_module("raytracer-go_amd.backend")
+
+
+def make_scene(seed):
+    rng = np.random.default_rng(9000 + seed)
+    off = np.array([[0, 0, 0], [300, -200, 100], [5e3, 5e3, -5e3], [1e5, -1e5, 1e5]][seed % 4], dtype=float)
+    scale = [1.0, 0.01, 100.0][seed % 3]  # scene size: centimetres to hundreds of units
+    kind = seed % 5
+    n = 64 + 16 * (seed % 4)
+    u, v = np.meshgrid(np.linspace(-3, 3, n), np.linspace(-3, 3, n), indexing="ij")
+    if kind == 0:    # bumpy sheet
+        y = 1.2 + 0.3 * np.sin(2.1 * u + seed) * np.cos(1.7 * v)
+        P = np.stack([u, y, v], -1)
+    elif kind == 1:  # tilted, rippled plane (thin slabs at 45 degrees)
+        y = 1.5 + 0.7 * u + 0.02 * np.sin(9 * v)
+        P = np.stack([u, y, v], -1)
+    elif kind == 2:  # cylinder shell (curved: thick slabs for wide leaves)
+        a = (u + 3) / 6 * 2 * np.pi
+        P = np.stack([1.5 * np.cos(a), 1.6 + 1.5 * np.sin(a) * 0.6, v], -1)
+    elif kind == 3:  # noisy sheet (normals all over)
+        y = 1.0 + 0.15 * rng.normal(size=u.shape)
+        P = np.stack([u, y, v], -1)
+    else:            # two crossing sheets
+        y = 1.2 + 0.4 * np.sin(1.3 * u)
+        P = np.stack([u, y, v], -1)
+    a_, b_, c_, d_ = P[:-1, :-1], P[1:, :-1], P[:-1, 1:], P[1:, 1:]
+    tri = np.concatenate([np.stack([a_, b_, c_], -2).reshape(-1, 3, 3), np.stack([d_, c_, b_], -2).reshape(-1, 3, 3)])
+    if kind == 4:
+        Q = np.stack([u, 1.2 + 0.5 * v / 3, v], -1)
+        a_, b_, c_, d_ = Q[:-1, :-1], Q[1:, :-1], Q[:-1, 1:], Q[1:, 1:]
+        tri = np.concatenate([tri, np.stack([a_, b_, c_], -2).reshape(-1, 3, 3), np.stack([d_, c_, b_], -2).reshape(-1, 3, 3)])
+    tri = tri * scale + off
+    V = lambda x, y_, z: api.Vec(float(x * scale + off[0]), float(y_ * scale + off[1]), float(z * scale + off[2]))
+    mat = api.PhongBlinn(ColorFrac=api.Vec(0.8, 0.7, 0.6), SpecularColorFrac=api.Vec(1, 1, 1), SpecHardness=16)
+    floor = api.PhongBlinn(ColorFrac=api.Vec(0.6, 0.6, 0.6), SpecularColorFrac=api.Vec(0.3, 0.3, 0.3), SpecHardness=4)
+    R = 9.0
+    shapes = [api.TrianglePlane(V(-R, 0, -R), V(-R, 0, R), V(R, 0, -R), False, floor),
+              api.TrianglePlane(V(R, 0, R), V(R, 0, -R), V(-R, 0, R), False, floor),
+              api.TriangleMesh(tri, bool(seed & 1), mat)]
+    for k in range(5):
+        p = rng.uniform(-2.5, 2.5, 3)
+        shapes.append(api.Sphere(V(p[0], 1.3 + 0.2 * k, p[2]), float(rng.uniform(0.05, 0.4)) * scale, mat))
+    # (the soft-shadow jitter is 0.25 units whatever the scene's size: at scale 0.01 the light's ball dwarfs the scene)
+    lights = [api.AmbientLight(api.Vec(1, 1, 1), 0.05),
+              api.PointLight(ColorFrac=api.Vec(1, 1, 1), Position=V(6, 2.0 + 3 * (seed % 2), -5), LightIntensity=60 * scale * scale, SpecularLightIntensity=20,
+                             InverseSquareLawDecayFactor=0.5),
+              api.SpotLight(ColorFrac=api.Vec(0.8, 0.9, 1), Position=V(-1, 6, 1), LightIntensity=40 * scale * scale, SpecularLightIntensity=10,
+                            LookAt=V(0, 1, 0), Angle=25.0 + 10 * (seed % 3), InverseSquareLawDecayFactor=0.3)]
+    spec = api.ImageSpec(160, 100, 2, 4, 16, 16, api.Dijkstra)
+    scene = api.Scene(V(0, 2.2, -7), V(0, 1.2, 0), api.Vec(0, 1, 0), V(0, 1.2, 0), 0.02 * scale, 50.0, shapes, lights)
+    return spec, scene, kind, scale, off
+
+
+def check(seed, parts=False):
+    """True if the scene of `seed` renders bit-identically with and without the conservative bounds."""
+    spec, scene, kind, scale, off = make_scene(seed)
+    with backend.DeviceScene(scene) as dev:
+        os.environ["RTGO_BEAM"] = "1"
+        got, st = dev.render_accum(spec)
+        os.environ["RTGO_SLAB"] = "0"; os.environ["RTGO_BEAM"] = "0"
+        want, st0 = dev.render_accum(spec)
+        del os.environ["RTGO_SLAB"]; del os.environ["RTGO_BEAM"]
+        if parts:  # which bound is it?
+            found = {}
+            for name, env in (("slabs only", {"RTGO_BEAM": "0"}), ("beams only", {"RTGO_BEAM": "1", "RTGO_SLAB": "0", "RTGO_VOXEL": "0"}),
+                              ("beams + voxels, no slabs", {"RTGO_BEAM": "1", "RTGO_SLAB": "0"}), ("beams + slabs, no voxels", {"RTGO_BEAM": "1", "RTGO_VOXEL": "0"}),
+                              ("beams only, rays from the root", {"RTGO_BEAM": "1", "RTGO_SLAB": "0", "RTGO_VOXEL": "0", "RTGO_RESUME": "0"})):
+                os.environ.update(env)
+                x, _ = dev.render_accum(spec)
+                for k in env:
+                    del os.environ[k]
+                found[name] = int((x != want).any(axis=-1).sum())
+            print("   pixels that differ:", found)
+    same = bool(np.array_equal(got, want)) and st.rays_shadow == st0.rays_shadow
+    print(f"seed {seed}: kind {kind} scale {scale} offset {off.tolist()} -> {'same' if same else 'DIFFERENT %g' % float(np.abs(got - want).max())}; "
+          f"beams decide {st.rays_shadow_beam} of {st.rays_shadow}, {st.beam_walks} walks", flush=True)
+    return same
+
+
+if __name__ == "__main__":
+    n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    only = os.environ.get("STRESS_ONLY")
+    bad = 0
+    for seed in range(n_scenes):
+        if only and str(seed) not in only.split(","):
+            continue
+        bad += 0 if check(seed, parts=bool(os.environ.get("STRESS_PARTS"))) else 1
+    print("scenes that differ:", bad)
+    sys.exit(1 if bad else 0)
