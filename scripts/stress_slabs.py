@@ -36,6 +36,10 @@ def make_scene(seed):
         Q = np.stack([u, 1.2 + 0.5 * v / 3, v], -1)
         a_, b_, c_, d_ = Q[:-1, :-1], Q[1:, :-1], Q[:-1, 1:], Q[1:, 1:]
         tri = np.concatenate([tri, np.stack([a_, b_, c_], -2).reshape(-1, 3, 3), np.stack([d_, c_, b_], -2).reshape(-1, 3, 3)])
+    if seed % 7 == 6:  # a soup instead: random triangles of all sizes and orientations (no surface for a slab to follow)
+        n_tri = 600 + 37 * (seed % 11)
+        c = rng.uniform(-3, 3, (n_tri, 1, 3)) * np.array([1.0, 0.5, 1.0]) + np.array([0.0, 2.0, 0.0])
+        tri = c + rng.normal(0, 0.05 + 0.04 * (seed % 5), (n_tri, 3, 3))
     tri = tri * scale + off
     V = lambda x, y_, z: api.Vec(float(x * scale + off[0]), float(y_ * scale + off[1]), float(z * scale + off[2]))
     mat = api.PhongBlinn(ColorFrac=api.Vec(0.8, 0.7, 0.6), SpecularColorFrac=api.Vec(1, 1, 1), SpecHardness=16)
@@ -53,7 +57,11 @@ def make_scene(seed):
                              InverseSquareLawDecayFactor=0.5),
               api.SpotLight(ColorFrac=api.Vec(0.8, 0.9, 1), Position=V(-1, 6, 1), LightIntensity=40 * scale * scale, SpecularLightIntensity=10,
                             LookAt=V(0, 1, 0), Angle=25.0 + 10 * (seed % 3), InverseSquareLawDecayFactor=0.3)]
-    spec = api.ImageSpec(160, 100, 2, 4, 16, 16, api.Dijkstra)
+    if seed % 5 == 3:  # a light among the shapes, and a mirror so that later bounces shade too
+        lights.append(api.PointLight(ColorFrac=api.Vec(1, 0.8, 0.8), Position=V(0.3, 1.25, 0.2), LightIntensity=10 * scale * scale, SpecularLightIntensity=5,
+                                     InverseSquareLawDecayFactor=0.5))
+        shapes.append(api.TrianglePlane(V(-R, 0, R), V(-R, 8, R), V(R, 0, R), True, api.Metal(api.Vec(0.9, 0.9, 0.9), 0.0)))
+    spec = api.ImageSpec(160, 100, 2, 4, (16, 1, 5, 70, 16, 3)[seed % 6], 16, api.Dijkstra)
     scene = api.Scene(V(0, 2.2, -7), V(0, 1.2, 0), api.Vec(0, 1, 0), V(0, 1.2, 0), 0.02 * scale, 50.0, shapes, lights)
     return spec, scene, kind, scale, off
 
