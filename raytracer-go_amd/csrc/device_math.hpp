@@ -98,6 +98,7 @@ struct DScene {
     const uint8_t* vox;              // per positional light and cell of a grid over the scene's box: 1 = every ray from any point of the
                                      // cell to any jittered position of the light is unoccluded (k_voxel_beams); nullptr: no grid
     float vox_min[3], vox_cs, vox_inv_cs;
+    float beam_r, beam_n1, beam_3n1;  // radius of the ball round a positional light that holds every jittered (and rounded) light position (pair beams, voxel beams), and 1.00001 / 3.00003 times that
     int vox_n[3];
     const DMaterial* materials;
     const DTexture* textures;
@@ -829,7 +830,7 @@ static_assert(kPendCap >= 8, "beam_store_origin() uses nine of the leaf-queue wo
 // parameters inside the box; no ray of the beam { p + s (D + j), |j_a| <= R } is between the slab's planes there if the
 // range of n . (x - box.min) over the beam's points misses [dmin, dmax]: at parameter s that range is
 // n . (p - box.min) + s (n . D -/+ R |n|_2), linear in s, so the two ends of [lo, hi] bound it.
-RT_DEV bool beam_meets_leaf(const DScene& S, const TraceStack& st, uint32_t first_shape, const Beam& bm, float R) {
+RT_DEV bool beam_meets_leaf(const DScene& S, const TraceStack& st, uint32_t first_shape, const Beam& bm) {
     const float4* const lb = S.leaf_bound + kLeafBoundQuads * (size_t)first_shape;
     const float4 a = lb[0], b = lb[1], c = lb[2], q3 = lb[3];
     const uint32_t* const w = st.lds + kLdsStackDepth * st.lds_stride;
@@ -846,14 +847,16 @@ RT_DEV bool beam_meets_leaf(const DScene& S, const TraceStack& st, uint32_t firs
     const f3 n = mk3(b.z, b.w, c.x);
     const f3 rel = mk3(p.x - a.x, p.y - a.y, p.z - a.z);
     const float nob = dotf(n, rel), nD = dotf(n, D);
-    const float n1 = R * 1.00001f;  // the jittered light positions lie in the BALL of radius 0.25 < R (light.go:94), so |n . j| <= R |n|_2, and |n|_2 <= 1 + 2^-22
+    // the jittered light positions lie in the BALL of radius R = S.beam_r (light.go:94: 0.25, + the rounding of light + jitter), so
+    // |n . j| <= R |n|_2, and |n|_2 <= 1 + 2^-22: n1 = S.beam_n1 = 1.00001 R (a scalar of the scene, so it costs the walk no register)
+    const float n1 = S.beam_n1;
     const float s_a = lo - 64.0f * kSlabMargin * fabsf(lo), s_b = hi + 64.0f * kSlabMargin * fabsf(hi);
     // (a beam that starts from a box: its points at s have n . (x - box.min) within (1 - s) (n . rel -/+ e) + s (n . rel + n . D -/+ n1),
     // e = the box's half extent along n)
     const float e1 = (fabsf(n.x) * h.x + fabsf(n.y) * h.y) + fabsf(n.z) * h.z;
     const float vlo = fminf(fmaf(s_a, (nD - n1) + e1, nob - e1), fmaf(s_b, (nD - n1) + e1, nob - e1));
     const float vhi = fmaxf(fmaf(s_a, (nD + n1) - e1, nob + e1), fmaf(s_b, (nD + n1) - e1, nob + e1));
-    const float m = kSlabMargin * ((((fabsf(rel.x) + fabsf(rel.y)) + fabsf(rel.z)) + ((h.x + h.y) + h.z)) + s_b * (((fabsf(D.x) + fabsf(D.y)) + fabsf(D.z)) + 3.0f * R));
+    const float m = kSlabMargin * ((((fabsf(rel.x) + fabsf(rel.y)) + fabsf(rel.z)) + ((h.x + h.y) + h.z)) + s_b * (((fabsf(D.x) + fabsf(D.y)) + fabsf(D.z)) + S.beam_3n1));
     if (vhi + m < c.y || vlo - m > c.z) return false;
 #if !RTGO_BEAM_SLAB2
     (void)q3;
@@ -867,7 +870,7 @@ RT_DEV bool beam_meets_leaf(const DScene& S, const TraceStack& st, uint32_t firs
     const float whi = fmaxf(fmaf(s_a, (nD2 + n1) - e2, nob2 + e2), fmaf(s_b, (nD2 + n1) - e2, nob2 + e2));
     return !(whi + m < q3.z || wlo - m > q3.w);
 }
-RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, const Beam& bm, float R, uint32_t* cur_out, int* sp_out) {
+RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, const Beam& bm, uint32_t* cur_out, int* sp_out) {
     uint32_t cur = 0u;  // block index; the root is block 0
     int sp = 0;
     bool walking = live, clear = true;
@@ -894,7 +897,7 @@ RT_DEV bool beam_is_clear(const DScene& S, const TraceStack& st, bool live, cons
                     while (leaf_hits && !met) {
                         const int k = __ffs((int)leaf_hits) - 1;
                         leaf_hits &= leaf_hits - 1u;
-                        met = beam_meets_leaf(S, st, h1.y + (((k < 4 ? p_lo : p_hi) >> ((uint32_t)(k & 3) * 8u)) & 0xffu), bm, R);
+                        met = beam_meets_leaf(S, st, h1.y + (((k < 4 ? p_lo : p_hi) >> ((uint32_t)(k & 3) * 8u)) & 0xffu), bm);
                     }
                 } else {
                     const uint32_t first = S.block_first[cur];

@@ -529,7 +529,11 @@ __global__ __launch_bounds__(kBlock) void k_pair_compact(Work Wk, const uint32_t
 #ifndef RTGO_BEAM_WAVES
 #define RTGO_BEAM_WAVES 7  // frame ms at config 3: 5 waves (86 VGPRs, the compiler's own choice) 308-310, 6 (78) 307.5, 7 (72) 303.5-304.2; the block's 20.5 KB of LDS allow no 8th
 #endif
-constexpr float kBeamR = 0.25f * 1.0001f + 1e-5f;  // half-width of the cube that holds every jittered light position (light.go:94), with margin
+constexpr float kBeamR = 0.25f * 1.0001f + 1e-5f;  // radius of the ball that holds every jittered light position (light.go:94), with margin
+// ... and the jittered position is ROUNDED: light + jitter in float32 is up to half an ulp of the light's coordinates off per
+// axis (0.00024 at 5,000 units from the origin: more than the margin above, and many times the thickness of a flat leaf's
+// slab).  DScene::beam_r = kBeamR + 2^-22 of the largest sum of a positional light's coordinates, over four times that
+// (one radius per scene: a scalar, where a radius per light would be one more register across the beam's walk).
 __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S, Batch B, Work Wk, const uint32_t* n_hits_ptr, const uint32_t* pair_counter) {
     __shared__ uint32_t s_stack[kLdsPerLane * kBlock];
     (void)n_hits_ptr;
@@ -565,14 +569,14 @@ __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_pair_beam(DScene S,
             inside = surely_inside_cone(L, p);
             judge = inside || Wk.beam_state != nullptr;
             if (judge) {
-                bm = make_beam(p, ld3(L.pos), kBeamR, 0.01f);
+                bm = make_beam(p, ld3(L.pos), S.beam_r, 0.01f);
                 beam_store_origin(st, p, sub3(ld3(L.pos), p));
             }
         }
         uint32_t stop_block = 0;
         int stop_sp = 0;
         walks += (unsigned long long)__popcll(__ballot(judge));
-        const bool beam_clear = beam_is_clear(S, st, judge, bm, kBeamR, &stop_block, &stop_sp) && judge;
+        const bool beam_clear = beam_is_clear(S, st, judge, bm, &stop_block, &stop_sp) && judge;
         const bool clear = beam_clear && inside;
         if (clear) {
             Wk.vis[(size_t)hit_i * S.n_pos_lights + lp] = (uint32_t)B.reps;
@@ -737,12 +741,12 @@ __global__ __launch_bounds__(kBlock, RTGO_BEAM_WAVES) void k_voxel_beams(DScene 
             const f3 ctr = mk3(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z));
             // (half extents a little over hi - ctr: the centre is rounded)
             const f3 h = mk3((hi.x - lo.x) * 0.50001f, (hi.y - lo.y) * 0.50001f, (hi.z - lo.z) * 0.50001f);
-            bm = make_box_beam(lo, hi, L, kBeamR, 0.01f);
+            bm = make_box_beam(lo, hi, L, S.beam_r, 0.01f);
             beam_store_origin(st, ctr, sub3(L, ctr), h);
         }
         uint32_t stop_block = 0;
         int stop_sp = 0;
-        const bool clear = beam_is_clear(S, st, live, bm, kBeamR, &stop_block, &stop_sp);
+        const bool clear = beam_is_clear(S, st, live, bm, &stop_block, &stop_sp);
         if (live) vox[i] = clear ? 1 : 0;
     }
 }
@@ -839,6 +843,18 @@ __global__ __launch_bounds__(kBlock, RTGO_SHADOW_WAVES) void k_shadow(DScene S, 
             prof_prev_visits = pv; prof_prev_iters = pit;
 #else
             const bool occ = occluded<true>(S, st, traced, p, dir, 0.01f, dist, resume);
+#endif
+#ifdef RTGO_DEBUG_CHECK
+            {   // every ray again from the root, without slabs: what do the bounds get wrong?
+                DScene S2 = S;
+                S2.leaf_bound = nullptr;
+                const bool want_ray = traced || beam_clear;
+                const bool occ2 = occluded<true>(S2, st, want_ray, p, dir, 0.01f, dist, nullptr);
+                const bool vis1 = (traced && !occ) || beam_clear, vis2 = want_ray && !occ2;
+                if (vis1 != vis2)
+                    printf("WRONG pair %u rep %u: visible %d, in truth %d; beam_clear %d resume0 %08x p %.9g %.9g %.9g dir %.9g %.9g %.9g dist %.9g\n",
+                           pi, rep, (int)vis1, (int)vis2, (int)beam_clear, resume ? resume[0] : 0u, p.x, p.y, p.z, dir.x, dir.y, dir.z, dist);
+            }
 #endif
             // the visible repetitions of a (hit, light) counted over its lane group: an integer, no summation order
             const unsigned long long m = __ballot((traced && !occ) || beam_clear);
@@ -1637,6 +1653,14 @@ static int finish_scene(const rt_scene_desc* desc, const HostScene& h, rt_scene*
     s->d.lights = (const DLight*)s->d_lights;
     s->d.pos_lights = s->d.lights + desc->n_lights + 1;
     s->d.n_lights = (int)desc->n_lights; s->d.n_pos_lights = h.n_pos; s->d.root_ref = h.flat.root_ref;
+    s->d.beam_r = kBeamR;
+    for (int l = 0; l < h.n_pos; ++l) {
+        const DLight& pl = h.lights[(size_t)desc->n_lights + 1 + (size_t)l];
+        const float sum = (std::fabs(pl.pos[0]) + std::fabs(pl.pos[1])) + std::fabs(pl.pos[2]);
+        if (std::isfinite(sum)) s->d.beam_r = std::max(s->d.beam_r, kBeamR + 2.384185791015625e-07f * sum);
+    }
+    s->d.beam_n1 = s->d.beam_r * 1.00001f;
+    s->d.beam_3n1 = 3.0f * s->d.beam_n1;
     // The voxel beams (device_math.hpp): a grid of at most 128 cubic cells a side over the box of the tree's top block,
     // one beam per positional light and cell, walked here once.  Only for scenes that get pair beams by default (256
     // shapes or more), with slabs, and few enough lights for 32 MiB of cells (RTGO_VOXEL=0: none).

@@ -1,6 +1,8 @@
 """Stress of the conservative bounds (leaf slabs, pair beams, voxel beams): seeded random scenes rendered with everything
 on and with RTGO_SLAB=0 RTGO_BEAM=0 (every shadow ray walked, every shape of every leaf met tested); the accumulation
-buffers must be bit-identical.  Run on the GPU box: python scripts/stress_slabs.py [scenes]"""
+buffers must be bit-identical.  Run on the GPU box: python scripts/stress_slabs.py [scenes [first seed]]
+(seeds from 10000 on: flat axis-aligned sheets, degenerate and duplicate triangles, needles and scene-sized triangles in
+a fine mesh, folded sheets)"""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -36,7 +38,36 @@ def make_scene(seed):
         Q = np.stack([u, 1.2 + 0.5 * v / 3, v], -1)
         a_, b_, c_, d_ = Q[:-1, :-1], Q[1:, :-1], Q[:-1, 1:], Q[1:, 1:]
         tri = np.concatenate([tri, np.stack([a_, b_, c_], -2).reshape(-1, 3, 3), np.stack([d_, c_, b_], -2).reshape(-1, 3, 3)])
-    if seed % 7 == 6:  # a soup instead: random triangles of all sizes and orientations (no surface for a slab to follow)
+    if seed >= 10000:  # pathological inputs (seeds from 10000 on; the scenes of the seeds below stay as they were)
+        kind = 5 + (seed // 4) % 4  # (seed % 4 picks the offset)
+        if kind == 5:    # exactly flat, axis-aligned sheets and walls: boxes and slabs of zero thickness
+            Pf = np.stack([u, np.full_like(u, 1.25), v], -1)
+            Pw = np.stack([np.full_like(u, 0.5), 1.5 + 0.4 * u, v], -1)
+            tri = np.concatenate([np.concatenate([np.stack([X[:-1, :-1], X[1:, :-1], X[:-1, 1:]], -2).reshape(-1, 3, 3),
+                                                  np.stack([X[1:, 1:], X[:-1, 1:], X[1:, :-1]], -2).reshape(-1, 3, 3)]) for X in (Pf, Pw)])
+        elif kind == 6:  # degenerate triangles among the others: repeated vertices, collinear vertices, exact duplicates
+            t = tri.copy()
+            idx = rng.permutation(len(t))
+            q = len(t) // 8
+            t[idx[:q], 1] = t[idx[:q], 0]                                 # two vertices equal
+            t[idx[q:2 * q], 2] = 2 * t[idx[q:2 * q], 1] - t[idx[q:2 * q], 0]  # collinear
+            t[idx[2 * q:3 * q]] = t[idx[3 * q:4 * q]]                     # the same triangle twice
+            t[idx[4 * q:4 * q + 8]] = t[idx[4 * q:4 * q + 8], :1]         # a point
+            tri = t
+        elif kind == 7:  # sizes mixed in one tree: needles and slivers through a fine mesh, a few triangles as large as the scene
+            n_big = 24
+            c = rng.uniform(-2.5, 2.5, (n_big, 1, 3)) * np.array([1.0, 0.3, 1.0]) + np.array([0.0, 1.6, 0.0])
+            d = rng.normal(0, 1, (n_big, 1, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+            w = rng.normal(0, 1, (n_big, 1, 3)) * 1e-3
+            needles = np.concatenate([c - 2.5 * d, c + 2.5 * d, c + w], 1)
+            big = rng.uniform(-3, 3, (6, 3, 3)) * np.array([1.0, 0.2, 1.0]) + np.array([0.0, 2.4, 0.0])
+            tri = np.concatenate([tri, needles, big])
+        else:            # a sheet folded back on itself many times: normals cancel in many leaves (no slab), coplanar layers
+            y = 1.2 + 0.05 * np.abs(((u * 8) % 2) - 1)
+            P2 = np.stack([u, y, v], -1)
+            tri = np.concatenate([tri, np.stack([P2[:-1, :-1], P2[1:, :-1], P2[:-1, 1:]], -2).reshape(-1, 3, 3),
+                                  np.stack([P2[1:, 1:], P2[1:, :-1], P2[:-1, 1:]], -2).reshape(-1, 3, 3)])
+    elif seed % 7 == 6:  # a soup instead: random triangles of all sizes and orientations (no surface for a slab to follow)
         n_tri = 600 + 37 * (seed % 11)
         c = rng.uniform(-3, 3, (n_tri, 1, 3)) * np.array([1.0, 0.5, 1.0]) + np.array([0.0, 2.0, 0.0])
         tri = c + rng.normal(0, 0.05 + 0.04 * (seed % 5), (n_tri, 3, 3))
@@ -94,9 +125,10 @@ def check(seed, parts=False):
 
 if __name__ == "__main__":
     n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 10000: the pathological scenes
     only = os.environ.get("STRESS_ONLY")
     bad = 0
-    for seed in range(n_scenes):
+    for seed in range(first, first + n_scenes):
         if only and str(seed) not in only.split(","):
             continue
         bad += 0 if check(seed, parts=bool(os.environ.get("STRESS_PARTS"))) else 1

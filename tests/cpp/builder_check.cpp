@@ -99,9 +99,12 @@ static void walk_q(const FlatTree& t, uint32_t ref, uint32_t blk, size_t* visite
             CHECK(e >= 1 && e <= 254, "qblock %u: exponent %d", blk, e);
             const double step = std::ldexp(1.0, e - 127);
             const double lo = (double)origin[a] + qlo[8 * a + o] * step, hi = (double)origin[a] + qhi[8 * a + o] * step;
-            CHECK(lo <= (double)r.bmin[a] && hi >= (double)r.bmax[a], "qblock %u slot %d axis %d: [%g, %g] does not enclose [%g, %g]", blk, o, a, lo, hi,
-                  (double)r.bmin[a], (double)r.bmax[a]);
-            CHECK((double)r.bmin[a] - lo < step && hi - (double)r.bmax[a] < step, "qblock %u slot %d axis %d: more than one grid step of slack", blk, o, a);
+            // the quantised box holds the record's box grown by t.qpad (the slab test's error far from the origin), and no more
+            // than that + one grid step + the rounding of the block's origin to float32
+            CHECK(lo <= (double)r.bmin[a] - t.qpad && hi >= (double)r.bmax[a] + t.qpad, "qblock %u slot %d axis %d: [%g, %g] does not enclose [%g, %g] grown by %g", blk, o, a, lo, hi,
+                  (double)r.bmin[a], (double)r.bmax[a], t.qpad);
+            const double most = step + t.qpad + std::fabs((double)origin[a]) * 1.1920928955078125e-07;
+            CHECK((double)r.bmin[a] - lo < most && hi - (double)r.bmax[a] < most, "qblock %u slot %d axis %d: more than one grid step of slack", blk, o, a);
         }
         if (r.w1 & kLeafFlag) {
             leafm |= 1u << o;

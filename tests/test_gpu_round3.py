@@ -295,3 +295,19 @@ def test_conservative_bounds_far_from_the_origin_and_at_small_scales():
     spec.loader.exec_module(mod)
     bad = [seed for seed in (0, 2, 3, 5, 7, 10, 11, 15, 19, 22, 31, 34, 39, 43, 51, 55, 59, 64, 77, 90) if not mod.check(seed)]
     assert not bad, bad
+
+
+def test_conservative_bounds_on_pathological_meshes():
+    """The same script's seeds from 10000 on: exactly flat, axis-aligned sheets and walls (boxes and slabs of zero thickness, rays
+    through the shared faces of leaves), triangles with repeated or collinear vertices and exact duplicates, needles and
+    scene-sized triangles through a fine mesh, sheets folded on themselves; at the same offsets and scales.  Seed 10050 found
+    that the quantised boxes of the shadow rays' walk were not conservative against the triangle test far from the origin
+    (the pre-rounded o / d of the slab test): a ray through the shared face of two leaves, 5,000 units out, missed both boxes
+    from the root and hit the triangle when its walk started below them.  The quantised boxes are now grown by 2^-19 of the
+    scene's largest coordinate (octree.cpp write_qblock), and a beam's radius by the rounding of light + jitter."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("stress_slabs", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "stress_slabs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = [seed for seed in (10050, 10000, 10003, 10005, 10010, 10013, 10022, 10027, 10034, 10040, 10047, 10002, 10019, 10049, 10063, 10095) if not mod.check(seed)]
+    assert not bad, bad
