@@ -324,12 +324,14 @@ inline float round_up(double x) {
     if ((double)f < x) f = std::nextafterf(f, INFINITY);
     return f;
 }
-void fill_f32_boxes(Node* n) {
-    n->fmin[0] = round_down(n->pmin.x); n->fmin[1] = round_down(n->pmin.y); n->fmin[2] = round_down(n->pmin.z);
-    n->fmax[0] = round_up(n->pmax.x);   n->fmax[1] = round_up(n->pmax.y);   n->fmax[2] = round_up(n->pmax.z);
+// pad: the device flattener grows every box by 2^-19 of the scene's largest coordinate before it rounds it outward, so that
+// the float32 slab test with its pre-rounded o / d is conservative against the shapes' own tests (octree.cpp flatten_octree)
+void fill_f32_boxes(Node* n, double pad) {
+    n->fmin[0] = round_down(n->pmin.x - pad); n->fmin[1] = round_down(n->pmin.y - pad); n->fmin[2] = round_down(n->pmin.z - pad);
+    n->fmax[0] = round_up(n->pmax.x + pad);   n->fmax[1] = round_up(n->pmax.y + pad);   n->fmax[2] = round_up(n->pmax.z + pad);
     n->count = (n->leaf && n->shape >= 0) ? 1 : 0;
     if (n->has_children)
-        for (Node* c : n->children) if (c) { fill_f32_boxes(c); n->count += c->count; }
+        for (Node* c : n->children) if (c) { fill_f32_boxes(c, pad); n->count += c->count; }
 }
 // shapes of a subtree, depth first in octant order (the order of a device leaf's shapes)
 void subtree_shapes(const Node* n, std::vector<int>* out) {
@@ -347,6 +349,14 @@ inline Node* effective(Node* n) {
     }
     return n;
 }
+// 2^-19 of the largest coordinate of the tree's box (the box of the first node that is not a single-child chain link)
+inline double box_pad(Node* root) {
+    const Node* e = effective(root);
+    double m = 0.0;
+    for (double v : {e->pmin.x, e->pmin.y, e->pmin.z, e->pmax.x, e->pmax.y, e->pmax.z}) m = std::fmax(m, std::fabs(v));
+    return std::isfinite(m) ? m * 1.9073486328125e-06 : 0.0;
+}
+void fill_f32_boxes(Node* n) { fill_f32_boxes(n, box_pad(n)); }
 
 // The device flattener's block of an effective inner node x (csrc/octree.cpp block_slots), restated:
 // slot o starts as the chain-skipped child of octant o; then, while some inner child (more than

@@ -815,26 +815,13 @@ static void block_slots(const HostNodes& nodes, int32_t x, const LeafRule& rule,
 }
 
 // The block whose child records are rec[0, count) (slot order, absent slots omitted), as a QBlock written to w.
-// pad: every quantised box is the child's box grown by `pad` on all sides before it is rounded outward to the grid.  The
-// device's slab test t = fma(q, step / d, fma(origin, 1 / d, -(o / d))) with its pre-rounded o / d places a plane up to
-// 2^-24 (|o| + |origin - o| + 2 |plane - o|) off — at most 7 M 2^-24 for origins and boxes within M of the world's origin
-// (a shadow ray starts on a shape) — while a triangle test, which subtracts a vertex from the ray's origin first, errs by
-// a few 2^-24 of the distance between the two: a ray through the shared face of two flat, axis-aligned leaves 5,000
-// units from the origin could miss both boxes and still pass either triangle's test, and the answer then depended on
-// where the walk started (scripts/stress_slabs.py, seed 10050: from the root "unoccluded", resumed below the blocks in
-// question "occluded").  With every plane moved outward by more than both errors (pad = 2^-19 M) each axis' computed
-// interval holds the true one, so a walk reaches every shape whose own test the ray can pass, wherever it starts.
-// The price is not the size of the pad but that it is not zero: a flat, axis-aligned leaf (a floor, a wall) is now one
-// grid step thick on either side, and the shadow rays that START on it enter it (config 3: + 2 % shape loops, + 0.4 %
-// frame time, whatever the pad).
-static void write_qblock(const ChildRecord* rec, int count, uint32_t present, uint32_t leaf_mask, uint32_t child_base, double pad, uint32_t* w) {
+// (The records' boxes are padded already: flatten_octree.)
+static void write_qblock(const ChildRecord* rec, int count, uint32_t present, uint32_t leaf_mask, uint32_t child_base, uint32_t* w) {
     for (int i = 0; i < kQBlockWords; ++i) w[i] = 0;
     float origin[3], top[3];
     for (int a = 0; a < 3; ++a) {
         origin[a] = rec[0].bmin[a]; top[a] = rec[0].bmax[a];
         for (int k = 1; k < count; ++k) { origin[a] = std::min(origin[a], rec[k].bmin[a]); top[a] = std::max(top[a], rec[k].bmax[a]); }
-        origin[a] = round_down_f32((double)origin[a] - pad);
-        top[a] = round_up_f32((double)top[a] + pad);
     }
     uint32_t exps = 0;
     double step[3];
@@ -868,8 +855,8 @@ static void write_qblock(const ChildRecord* rec, int count, uint32_t present, ui
             meta[o] = (uint8_t)(rank++ << 5);
         }
         for (int a = 0; a < 3; ++a) {
-            const double lo = std::floor((((double)r.bmin[a] - pad) - (double)origin[a]) / step[a]);
-            const double hi = std::ceil((((double)r.bmax[a] + pad) - (double)origin[a]) / step[a]);
+            const double lo = std::floor(((double)r.bmin[a] - (double)origin[a]) / step[a]);
+            const double hi = std::ceil(((double)r.bmax[a] - (double)origin[a]) / step[a]);
             qlo[8 * a + o] = (uint8_t)std::max(0.0, std::min(255.0, lo));
             qhi[8 * a + o] = (uint8_t)std::max(0.0, std::min(255.0, hi));
         }
@@ -902,14 +889,31 @@ bool flatten_octree(const HostNodes& nodes, int leaf_size, FlatTree* out, const 
     if (leaf_size < 1) leaf_size = 1;
     if (leaf_size > kMaxLeafSize) leaf_size = kMaxLeafSize;
 
-    auto set_box = [&](int32_t e, ChildRecord* r) {
-        for (int a = 0; a < 3; ++a) { r->bmin[a] = round_down_f32(nodes[e].lo[a]); r->bmax[a] = round_up_f32(nodes[e].hi[a]); }
-    };
+    // Every box of the flat tree is the node's box grown by `qpad` = 2^-19 of the scene's largest coordinate M, then rounded
+    // outward to float32.  The device's slab test t = fma(plane, 1 / d, -(o / d)) rounds o / d before the subtraction and
+    // so places a plane up to 2^-24 (|o| + 2 |plane - o|) off — 5 M 2^-24 at most for origins and boxes within M of the
+    // world's origin (a secondary ray starts on a shape; the quantised form of the shadow rays' walk, fma(q, step / d,
+    // fma(origin, 1 / d, -(o / d))), adds |origin - o|: 7 M 2^-24) — while a shape's own test, which subtracts a vertex or
+    // a centre from the ray's origin first, errs by a few 2^-24 of the distance between the two.  Far from the world's
+    // origin a ray could therefore miss a leaf's box and still pass the test of a shape inside it, and the answer
+    // depended on the path: scripts/stress_slabs.py, seed 10050 (flat sheets 5,000 units out) — a shadow ray through the
+    // shared face of two leaves missed both boxes from the root and hit the triangle when its walk resumed below them;
+    // and the same rays through the SAH tree with 20- and 4-shape leaves and through the octree: 1 answer in 1,000
+    // differed at 5,000 units.  With every plane moved outward by more than both errors each axis' computed interval
+    // holds the true one: a walk reaches every shape whose own test the ray can pass, wherever it starts and whatever
+    // the tree — the answer is the OR (the minimum) over the shapes' tests.  The oracle's float32 mode grows its boxes
+    // the same way (fill_f32_boxes).
+    // The price is not the size of the pad but that it is not zero: a flat, axis-aligned leaf (a floor, a wall) is now one
+    // grid step of its quantised block thick on either side, and the shadow rays that START on it enter it (config 3:
+    // + 2 % shape loops, + 0.4 % frame time, whatever the pad).
     const int32_t root = skip_chain(nodes, 0);
-    double qpad = 0.0;  // 2^-19 of the scene's largest coordinate (write_qblock)
+    double qpad = 0.0;
     for (int a = 0; a < 3; ++a) qpad = std::max(qpad, std::max(std::fabs(nodes[root].lo[a]), std::fabs(nodes[root].hi[a])));
     qpad = std::isfinite(qpad) ? qpad * 1.9073486328125e-06 : 0.0;
     out->qpad = qpad;
+    auto set_box = [&](int32_t e, ChildRecord* r) {
+        for (int a = 0; a < 3; ++a) { r->bmin[a] = round_down_f32(nodes[e].lo[a] - qpad); r->bmax[a] = round_up_f32(nodes[e].hi[a] + qpad); }
+    };
     const LeafRule rule{leaf_size, box_area(nodes[root]), std::getenv("RTGO_NO_COLLAPSE") == nullptr};
     if (is_leaf(nodes, root, rule)) {
         // everything fits one leaf: synthetic root block with that leaf in octant 0
@@ -922,7 +926,7 @@ bool flatten_octree(const HostNodes& nodes, int leaf_size, FlatTree* out, const 
         out->root_ref = (0u << 8) | 1u;
         out->n_inner = 1; out->depth = 1; out->stack_bound = 8;
         out->qblocks.resize(kQBlockWords);
-        write_qblock(out->records.data(), 1, 1u, 1u, 0u, qpad, out->qblocks.data());
+        write_qblock(out->records.data(), 1, 1u, 1u, 0u, out->qblocks.data());
         out->block_first.assign(1, 0u);
         out->block_box.assign(8, 0.0f);
         for (int a = 0; a < 3; ++a) { out->block_box[(size_t)a] = r.bmin[a]; out->block_box[(size_t)(4 + a)] = r.bmax[a]; }
@@ -1021,7 +1025,7 @@ bool flatten_octree(const HostNodes& nodes, int leaf_size, FlatTree* out, const 
                 ChildRecord* rec = recs + bt.first;
                 for (int k = 0; k < bt.count; ++k) rec[k].w1 |= bt.leaf_mask;
                 const uint32_t child_base = bt.inner ? (uint32_t)(run.pushed_base + bt.inner_before) : 0u;  // its first inner child's block
-                write_qblock(rec, bt.count, bt.present, bt.leaf_mask, child_base, qpad, out->qblocks.data() + block * kQBlockWords);
+                write_qblock(rec, bt.count, bt.present, bt.leaf_mask, child_base, out->qblocks.data() + block * kQBlockWords);
                 const uint32_t first = (uint32_t)(run.rec_base + bt.first);
                 const uint32_t ref = (first << 8) | bt.present;
                 const int64_t patch = level[run.b + j].patch;  // a record of the level above: final, and named by this block alone

@@ -122,7 +122,7 @@ struct FlatTree {
     int64_t n_inner = 0;    // blocks
     int32_t depth = 0;      // levels of blocks below the root (root block = 1)
     int32_t stack_bound = 1;  // exact worst case of the traversal stack for this tree
-    double qpad = 0.0;        // what every quantised box is grown by before it is rounded outward to its block's grid: 2^-19 of the scene's largest coordinate
+    double qpad = 0.0;        // what every box of the flat tree is grown by before it is rounded outward to float32: 2^-19 of the scene's largest coordinate
 };
 
 // shapes: desc->shapes[0..n). Returns nodes[0] = root.

@@ -2,7 +2,8 @@
 on and with RTGO_SLAB=0 RTGO_BEAM=0 (every shadow ray walked, every shape of every leaf met tested); the accumulation
 buffers must be bit-identical.  Run on the GPU box: python scripts/stress_slabs.py [scenes [first seed]]
 (seeds from 10000 on: flat axis-aligned sheets, degenerate and duplicate triangles, needles and scene-sized triangles in
-a fine mesh, folded sheets)"""
+a fine mesh, folded sheets; from 20000 on: lights inside their own jitter's reach of a surface, on a vertex, on the floor,
+eight lights with cones of 1 to 179 degrees, a sphere around everything, a light 300 scene sizes away, a scene without height)"""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -92,6 +93,32 @@ def make_scene(seed):
         lights.append(api.PointLight(ColorFrac=api.Vec(1, 0.8, 0.8), Position=V(0.3, 1.25, 0.2), LightIntensity=10 * scale * scale, SpecularLightIntensity=5,
                                      InverseSquareLawDecayFactor=0.5))
         shapes.append(api.TrianglePlane(V(-R, 0, R), V(-R, 8, R), V(R, 0, R), True, api.Metal(api.Vec(0.9, 0.9, 0.9), 0.0)))
+    if seed >= 20000:  # lights and extents at their limits (seeds from 20000 on; the mesh is the one of seed % 5)
+        var = (seed // 4) % 6
+        kind = 10 + var
+        if var == 0:    # a light closer to the surface than its own jitter: the hit point is inside the ball of light positions
+            k = int(rng.integers(len(tri)))
+            c = tri[k].mean(0)
+            lights.append(api.PointLight(ColorFrac=api.Vec(1, 1, 0.9), Position=api.Vec(float(c[0]), float(c[1] + 0.12), float(c[2])), LightIntensity=2 * scale * scale,
+                                         SpecularLightIntensity=1, InverseSquareLawDecayFactor=0.5))
+        elif var == 1:  # a light exactly on a vertex of the mesh, and one exactly on the floor
+            v0 = tri[int(rng.integers(len(tri)))][0]
+            lights.append(api.PointLight(ColorFrac=api.Vec(1, 1, 0.9), Position=api.Vec(float(v0[0]), float(v0[1]), float(v0[2])), LightIntensity=2 * scale * scale,
+                                         SpecularLightIntensity=1, InverseSquareLawDecayFactor=0.5))
+            lights.append(api.PointLight(ColorFrac=api.Vec(0.9, 1, 1), Position=V(1.0, 0.0, -1.0), LightIntensity=2 * scale * scale, SpecularLightIntensity=1,
+                                         InverseSquareLawDecayFactor=0.5))
+        elif var == 2:  # eight lights, cones from 1 to 179 degrees
+            for q, ang in enumerate((1.0, 5.0, 89.0, 90.0, 91.0, 179.0)):
+                lights.append(api.SpotLight(ColorFrac=api.Vec(0.5, 0.6, 0.7), Position=V(-2.5 + q, 4.0 + 0.3 * q, -2.0 + 0.7 * q), LightIntensity=20 * scale * scale,
+                                            SpecularLightIntensity=5, LookAt=V(0.2 * q, 1.0, 0.1 * q), Angle=ang, InverseSquareLawDecayFactor=0.3))
+        elif var == 3:  # everything inside one huge sphere, the mesh tiny against the scene's box
+            shapes.append(api.Sphere(V(0, 1, 0), 60.0 * scale, floor))
+        elif var == 4:  # a light far outside, 300 scene sizes away (beams as long as the coordinates allow)
+            lights.append(api.PointLight(ColorFrac=api.Vec(1, 1, 1), Position=V(900.0, 1500.0, -1200.0), LightIntensity=4e6 * scale * scale, SpecularLightIntensity=5,
+                                         InverseSquareLawDecayFactor=0.5))
+        else:           # only the floor and flat things on it: the scene's box has no height
+            shapes = shapes[:2] + [api.TrianglePlane(V(-1, 0, -1), V(-1, 0, 1), V(1, 0, -1), False, mat), api.TrianglePlane(V(0.5, 0, 0.5), V(2, 0, 0.7), V(0.7, 0, 2), False, mat)]
+            shapes += [api.TrianglePlane(V(0.01 * q - 2, 0, 0.013 * q), V(0.01 * q - 1.99, 0, 0.013 * q + 0.02), V(0.01 * q - 1.97, 0, 0.013 * q - 0.01), False, mat) for q in range(300)]
     spec = api.ImageSpec(160, 100, 2, 4, (16, 1, 5, 70, 16, 3)[seed % 6], 16, api.Dijkstra)
     scene = api.Scene(V(0, 2.2, -7), V(0, 1.2, 0), api.Vec(0, 1, 0), V(0, 1.2, 0), 0.02 * scale, 50.0, shapes, lights)
     return spec, scene, kind, scale, off
@@ -123,6 +150,49 @@ def check(seed, parts=False):
     return same
 
 
+def check_trees(seed, n_rays=40000):
+    """True if shadow-style any-hit rays through the scene of `seed` answer alike whatever tree they walk: the SAH tree with
+    leaves of 20 and of 4 shapes and the reference's octree put different boxes between a ray and a shape, and a walk whose
+    box tests are conservative against the shapes' own tests gives the OR of those tests over all shapes either way."""
+    spec, scene, kind, scale, off = make_scene(seed)
+    rng = np.random.default_rng(seed)
+    px = np.stack([rng.integers(0, spec.Width, n_rays), rng.integers(0, spec.Height, n_rays), rng.integers(0, spec.AntiAliasingFactor, n_rays)], 1).astype(np.int32)
+    lights = [l for l in scene.Lights if hasattr(l, "Position")]
+    answers, nearest, sh = [], [], None
+    for env in ({}, {"RTGO_LEAF_SIZE": "4"}, {"RTGO_TREE": "octree"}):
+        os.environ.update(env)
+        try:
+            with backend.DeviceScene(scene) as dev:
+                if sh is None:  # the rays: from the first tree's nearest hits towards jittered light positions, as k_shadow makes them
+                    rays = np.zeros((n_rays, 8), np.float32)
+                    rays[:, :6] = dev.camera_rays(spec, px)
+                    rays[:, 7] = 3.0e38
+                ids, t = dev.trace_rays(rays)
+                nearest.append(np.where(ids >= 0, t, np.float32(-1)))  # (two shapes at the same t: which one is named depends on the order)
+                if sh is None:
+                    hit = ids >= 0
+                    p = (rays[hit, :3] + t[hit, None] * rays[hit, 3:6]).astype(np.float32)
+                    L = np.array([[l.Position.X, l.Position.Y, l.Position.Z] for l in lights], np.float32)[rng.integers(0, len(lights), p.shape[0])]
+                    j = rng.normal(size=p.shape); j *= (rng.uniform(0, 1, (p.shape[0], 1)) ** (1 / 3)) / np.linalg.norm(j, axis=1, keepdims=True)
+                    shifted = (L + np.float32(0.25) * j.astype(np.float32)).astype(np.float32)
+                    d = (shifted - p).astype(np.float32)
+                    dist = np.sqrt((d * d).sum(1, dtype=np.float32)).astype(np.float32)
+                    ok = dist > 0
+                    sh = np.zeros((int(ok.sum()), 8), np.float32)
+                    sh[:, :3], sh[:, 3:6], sh[:, 6], sh[:, 7] = p[ok], d[ok] * (np.float32(1) / dist[ok])[:, None], 0.01, dist[ok]
+                occ, _ = dev.trace_rays(sh, any_hit=True, uniform_tmin=True)
+                answers.append(occ.copy())
+        finally:
+            for k in env:
+                del os.environ[k]
+    n_diff = [int((a != answers[0]).sum()) for a in answers[1:]]
+    t_diff = [int((a != nearest[0]).sum()) for a in nearest[1:]]
+    same = not any(n_diff) and not any(t_diff)
+    print(f"seed {seed}: kind {kind} scale {scale} offset {off.tolist()} -> {len(sh)} any-hit rays, {int(answers[0].sum())} occluded; "
+          f"answers that differ from the default tree's: leaves of 4 {n_diff[0]}, octree {n_diff[1]}; nearest hits of {n_rays} camera rays at another t: {t_diff[0]}, {t_diff[1]}", flush=True)
+    return same
+
+
 if __name__ == "__main__":
     n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 10000: the pathological scenes
@@ -130,6 +200,9 @@ if __name__ == "__main__":
     bad = 0
     for seed in range(first, first + n_scenes):
         if only and str(seed) not in only.split(","):
+            continue
+        if os.environ.get("STRESS_TREES"):
+            bad += 0 if check_trees(seed) else 1
             continue
         bad += 0 if check(seed, parts=bool(os.environ.get("STRESS_PARTS"))) else 1
     print("scenes that differ:", bad)

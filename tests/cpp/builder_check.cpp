@@ -68,7 +68,7 @@ static void walk(const FlatTree& t, uint32_t ref, int stack, const ChildRecord* 
                 double lo[3], hi[3];
                 bounds(shapes[(size_t)sh], lo, hi);
                 for (int a = 0; a < 3; ++a)
-                    CHECK((double)r.bmin[a] <= lo[a] && (double)r.bmax[a] >= hi[a], "leaf box misses shape %d on axis %d", sh, a);
+                    CHECK((double)r.bmin[a] <= lo[a] - t.qpad && (double)r.bmax[a] >= hi[a] + t.qpad, "leaf box misses shape %d grown by the pad on axis %d", sh, a);
             }
         } else {
             walk(t, r.w0, here, &r, seen, shapes, depth + 1);
@@ -99,12 +99,9 @@ static void walk_q(const FlatTree& t, uint32_t ref, uint32_t blk, size_t* visite
             CHECK(e >= 1 && e <= 254, "qblock %u: exponent %d", blk, e);
             const double step = std::ldexp(1.0, e - 127);
             const double lo = (double)origin[a] + qlo[8 * a + o] * step, hi = (double)origin[a] + qhi[8 * a + o] * step;
-            // the quantised box holds the record's box grown by t.qpad (the slab test's error far from the origin), and no more
-            // than that + one grid step + the rounding of the block's origin to float32
-            CHECK(lo <= (double)r.bmin[a] - t.qpad && hi >= (double)r.bmax[a] + t.qpad, "qblock %u slot %d axis %d: [%g, %g] does not enclose [%g, %g] grown by %g", blk, o, a, lo, hi,
-                  (double)r.bmin[a], (double)r.bmax[a], t.qpad);
-            const double most = step + t.qpad + std::fabs((double)origin[a]) * 1.1920928955078125e-07;
-            CHECK((double)r.bmin[a] - lo < most && hi - (double)r.bmax[a] < most, "qblock %u slot %d axis %d: more than one grid step of slack", blk, o, a);
+            CHECK(lo <= (double)r.bmin[a] && hi >= (double)r.bmax[a], "qblock %u slot %d axis %d: [%g, %g] does not enclose [%g, %g]", blk, o, a, lo, hi,
+                  (double)r.bmin[a], (double)r.bmax[a]);
+            CHECK((double)r.bmin[a] - lo < step && hi - (double)r.bmax[a] < step, "qblock %u slot %d axis %d: more than one grid step of slack", blk, o, a);
         }
         if (r.w1 & kLeafFlag) {
             leafm |= 1u << o;
