@@ -349,14 +349,16 @@ inline Node* effective(Node* n) {
     }
     return n;
 }
-// 2^-19 of the largest coordinate of the tree's box (the box of the first node that is not a single-child chain link)
-inline double box_pad(Node* root) {
+// 2^-19 of the largest coordinate a ray of the render can start at: the tree's box (the box of the first node that is not
+// a single-child chain link) and the camera's lens (flatten_octree's origin_reach)
+inline double box_pad(Node* root, const Scene& sc) {
     const Node* e = effective(root);
-    double m = 0.0;
+    double m = std::fmax(std::fmax(std::fabs(sc.cam_from.x), std::fabs(sc.cam_from.y)), std::fabs(sc.cam_from.z)) + std::fabs(sc.aperture) * 0.5;
+    if (!std::isfinite(m)) m = 0.0;
     for (double v : {e->pmin.x, e->pmin.y, e->pmin.z, e->pmax.x, e->pmax.y, e->pmax.z}) m = std::fmax(m, std::fabs(v));
     return std::isfinite(m) ? m * 1.9073486328125e-06 : 0.0;
 }
-void fill_f32_boxes(Node* n) { fill_f32_boxes(n, box_pad(n)); }
+void fill_f32_boxes(Node* n, const Scene& sc) { fill_f32_boxes(n, box_pad(n, sc)); }
 
 // The device flattener's block of an effective inner node x (csrc/octree.cpp block_slots), restated:
 // slot o starts as the chain-skipped child of octant o; then, while some inner child (more than
@@ -596,7 +598,7 @@ struct SahTree {
         return out;
     }
 };
-void fill_f32_boxes(Node* n);
+void fill_f32_boxes(Node* n, const Scene& sc);
 Node* build_wide_tree(Scene& sc, int leaf_size) {
     const int n = (int)sc.t64.shapes.size();
     if (n == 0) return nullptr;
@@ -610,7 +612,7 @@ Node* build_wide_tree(Scene& sc, int leaf_size) {
     }
     t.split(0, n);
     Node* root = t.widen(0);
-    fill_f32_boxes(root);
+    fill_f32_boxes(root, sc);
     return root;
 }
 
@@ -1300,7 +1302,7 @@ orc_scene* orc_scene_create(const rt_scene_desc* d) {
         delete o;
         return nullptr;
     }
-    fill_f32_boxes(sc.root);
+    fill_f32_boxes(sc.root, sc);
     build_blocks(sc.root, sc.leaf_size);
     sc.wide_root = build_wide_tree(sc, sc.leaf_size);
     if (sc.wide_root) build_blocks(sc.wide_root, sc.leaf_size);

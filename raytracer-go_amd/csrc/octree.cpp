@@ -874,7 +874,7 @@ int builder_threads() {
 // level's blocks are dealt to the threads in contiguous runs; every thread works its run's blocks out into arrays of
 // its own (slots, leaves, records with run-local indices, the next level's blocks); the runs' lengths are summed up
 // in order; then every thread moves its run to its place in the tree.  The result does not depend on the runs.
-bool flatten_octree(const HostNodes& nodes, int leaf_size, FlatTree* out, const char** err) {
+bool flatten_octree(const HostNodes& nodes, int leaf_size, FlatTree* out, const char** err, double origin_reach) {
     out->records.clear();
     out->qblocks.clear();
     out->order.clear();
@@ -889,8 +889,8 @@ bool flatten_octree(const HostNodes& nodes, int leaf_size, FlatTree* out, const 
     if (leaf_size < 1) leaf_size = 1;
     if (leaf_size > kMaxLeafSize) leaf_size = kMaxLeafSize;
 
-    // Every box of the flat tree is the node's box grown by `qpad` = 2^-19 of the scene's largest coordinate M, then rounded
-    // outward to float32.  The device's slab test t = fma(plane, 1 / d, -(o / d)) rounds o / d before the subtraction and
+    // Every box of the flat tree is the node's box grown by `qpad` = 2^-19 of the scene's largest coordinate M (over the
+    // shapes' box and the camera's lens, where the primary rays start: origin_reach), then rounded outward to float32.  The device's slab test t = fma(plane, 1 / d, -(o / d)) rounds o / d before the subtraction and
     // so places a plane up to 2^-24 (|o| + 2 |plane - o|) off — 5 M 2^-24 at most for origins and boxes within M of the
     // world's origin (a secondary ray starts on a shape; the quantised form of the shadow rays' walk, fma(q, step / d,
     // fma(origin, 1 / d, -(o / d))), adds |origin - o|: 7 M 2^-24) — while a shape's own test, which subtracts a vertex or
@@ -907,7 +907,7 @@ bool flatten_octree(const HostNodes& nodes, int leaf_size, FlatTree* out, const 
     // grid step of its quantised block thick on either side, and the shadow rays that START on it enter it (config 3:
     // + 2 % shape loops, + 0.4 % frame time, whatever the pad).
     const int32_t root = skip_chain(nodes, 0);
-    double qpad = 0.0;
+    double qpad = std::isfinite(origin_reach) ? std::fabs(origin_reach) : 0.0;
     for (int a = 0; a < 3; ++a) qpad = std::max(qpad, std::max(std::fabs(nodes[root].lo[a]), std::fabs(nodes[root].hi[a])));
     qpad = std::isfinite(qpad) ? qpad * 1.9073486328125e-06 : 0.0;
     out->qpad = qpad;

@@ -150,6 +150,7 @@ HostNodes build_sah(const rt_shape* shapes, int64_t n, int leaf_size);
 // Threads the builders and the flattener use: RTGO_BUILD_THREADS, by default the hardware's but at most 16.
 int builder_threads();
 // Returns false (and sets *err) if the tree exceeds kMaxChildRecords.
-bool flatten_octree(const HostNodes& nodes, int leaf_size, FlatTree* out, const char** err);
+// origin_reach: the largest coordinate a ray can start at outside the shapes' box (the camera's lens); the boxes' pad grows with it
+bool flatten_octree(const HostNodes& nodes, int leaf_size, FlatTree* out, const char** err, double origin_reach = 0.0);
 
 }  // namespace rtgo

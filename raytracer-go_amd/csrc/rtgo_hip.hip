@@ -1467,7 +1467,10 @@ static int build_host_scene(const rt_scene_desc* desc, HostScene* h, Laps& lap) 
                                                 ? build_octree(desc->shapes, desc->n_shapes)
                                                 : build_sah(desc->shapes, desc->n_shapes, leaf_size);
         lap("tree");
-        if (!flatten_octree(nodes, leaf_size, &h->flat, &err)) return fail(RT_ERR_LIMIT, err);
+        // (the boxes' pad covers the slab test's error for rays that start anywhere among the shapes or on the camera's lens)
+        const double lens_reach = std::max(std::max(std::fabs(desc->camera_look_from.x), std::fabs(desc->camera_look_from.y)), std::fabs(desc->camera_look_from.z)) +
+                                  std::fabs(desc->camera_aperture) * 0.5;
+        if (!flatten_octree(nodes, leaf_size, &h->flat, &err, lens_reach)) return fail(RT_ERR_LIMIT, err);
         lap("flatten");
     }
     lap("free nodes");

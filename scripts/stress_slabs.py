@@ -3,7 +3,7 @@ on and with RTGO_SLAB=0 RTGO_BEAM=0 (every shadow ray walked, every shape of eve
 buffers must be bit-identical.  Run on the GPU box: python scripts/stress_slabs.py [scenes [first seed]]
 (seeds from 10000 on: flat axis-aligned sheets, degenerate and duplicate triangles, needles and scene-sized triangles in
 a fine mesh, folded sheets; from 20000 on: lights inside their own jitter's reach of a surface, on a vertex, on the floor,
-eight lights with cones of 1 to 179 degrees, a sphere around everything, a light 300 scene sizes away, a scene without height)"""
+eight lights with cones of 1 to 179 degrees, a sphere around everything, a light 300 scene sizes away, a scene without height, a camera 20 scene sizes away)"""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -93,8 +93,9 @@ def make_scene(seed):
         lights.append(api.PointLight(ColorFrac=api.Vec(1, 0.8, 0.8), Position=V(0.3, 1.25, 0.2), LightIntensity=10 * scale * scale, SpecularLightIntensity=5,
                                      InverseSquareLawDecayFactor=0.5))
         shapes.append(api.TrianglePlane(V(-R, 0, R), V(-R, 8, R), V(R, 0, R), True, api.Metal(api.Vec(0.9, 0.9, 0.9), 0.0)))
+    far_camera = False
     if seed >= 20000:  # lights and extents at their limits (seeds from 20000 on; the mesh is the one of seed % 5)
-        var = (seed // 4) % 6
+        var = (seed // 4) % 7
         kind = 10 + var
         if var == 0:    # a light closer to the surface than its own jitter: the hit point is inside the ball of light positions
             k = int(rng.integers(len(tri)))
@@ -116,11 +117,22 @@ def make_scene(seed):
         elif var == 4:  # a light far outside, 300 scene sizes away (beams as long as the coordinates allow)
             lights.append(api.PointLight(ColorFrac=api.Vec(1, 1, 1), Position=V(900.0, 1500.0, -1200.0), LightIntensity=4e6 * scale * scale, SpecularLightIntensity=5,
                                          InverseSquareLawDecayFactor=0.5))
+        elif var == 6:  # the camera 20 scene sizes away behind a long lens: primary rays start far outside the shapes' box
+            far_camera = True
+            # (no spheres: Sphere.hit's b^2 - a c, kept in the reference's form, cancels in float32 when |o - centre|^2 nears 2^24
+            # r^2; from 700 units a 0.05-unit sphere "hits" rays that pass it by.  From 3,000 scene sizes the triangle test goes
+            # the same way — a triangle seen edge-on has a determinant below its own rounding (the reference's parallelism check
+            # is |det| < 0, shape.go:132) and reports hits hundreds of units in front of the scene, 7 rays in 40,000; from 100
+            # scene sizes 1 ray in 9 million; which of them a walk meets depends on its leaves.  float32 limits of the shapes'
+            # tests in the reference's expression order, not of the boxes: DESIGN section 5)
+            shapes = [sh for sh in shapes if not isinstance(sh, api.Sphere)]
         else:           # only the floor and flat things on it: the scene's box has no height
             shapes = shapes[:2] + [api.TrianglePlane(V(-1, 0, -1), V(-1, 0, 1), V(1, 0, -1), False, mat), api.TrianglePlane(V(0.5, 0, 0.5), V(2, 0, 0.7), V(0.7, 0, 2), False, mat)]
             shapes += [api.TrianglePlane(V(0.01 * q - 2, 0, 0.013 * q), V(0.01 * q - 1.99, 0, 0.013 * q + 0.02), V(0.01 * q - 1.97, 0, 0.013 * q - 0.01), False, mat) for q in range(300)]
     spec = api.ImageSpec(160, 100, 2, 4, (16, 1, 5, 70, 16, 3)[seed % 6], 16, api.Dijkstra)
     scene = api.Scene(V(0, 2.2, -7), V(0, 1.2, 0), api.Vec(0, 1, 0), V(0, 1.2, 0), 0.02 * scale, 50.0, shapes, lights)
+    if far_camera:
+        scene = api.Scene(V(0, 1.2 + 20.0, -140.0), V(0, 1.2, 0), api.Vec(0, 1, 0), V(0, 1.2, 0), 0.02 * scale, 2.7, shapes, lights)
     return spec, scene, kind, scale, off
 
 
