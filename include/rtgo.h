@@ -278,7 +278,11 @@ int rt_generate_image_multi(const rt_scene_desc* desc, const rt_image_spec* spec
  * ray slot 7 = tMax): prim_out = 1 if occluded else 0.  any_hit == 2: the same with ONE tMin for
  * the whole call (ray 0's slot 6; light.go:150 uses 0.01 for every shadow ray): the form of the
  * walk the render path itself runs, in which idle lanes of a wavefront walk subtrees for the
- * lanes that are still busy. */
+ * lanes that are still busy.
+ * The tree's boxes are grown by 2^-19 of the largest coordinate a ray of the render can start at (the
+ * shapes' box, the camera's lens), which makes the float32 box test conservative against the shapes'
+ * own tests for such rays; a ray given here that starts much farther from the world's origin than
+ * that walks boxes that are tighter than its own rounding. */
 int rt_trace_rays(rt_scene* scene, const float* rays, int64_t n, int32_t any_hit,
                   int32_t* prim_out, float* t_out);
 
