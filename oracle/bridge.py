@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "librtgo_oracle.so")
 
 F64_DIJKSTRA, F64_DFS, F32_STACK = 0, 1, 2
+F32_ALL_SHAPES = 3  # trace_rays only: the float32 shape tests over every shape, no tree
 
 _pkg = importlib.import_module("raytracer-go_amd")
 _abi = _pkg._abi

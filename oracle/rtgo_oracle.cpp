@@ -1337,8 +1337,10 @@ void orc_tree_info(const orc_scene* s, int64_t* out) {
 // rays: n * 8 doubles {o, d, tMin, tMax}.  prim_out: shape or -1 (any_hit: 1 occluded / 0).
 int orc_trace_rays(const orc_scene* s, int mode, const double* rays, int64_t n, int any_hit,
                    int32_t* prim_out, double* t_out, uint32_t* inner_out, uint32_t* leaf_out, int nthreads) {
-    if (mode < 0 || mode > 2) { g_err = "bad mode"; return -1; }
-    if (any_hit && mode != F32_STACK) { g_err = "any_hit is an F32_STACK probe"; return -1; }
+    // mode 3 (F32_ALL_SHAPES): no tree at all — the float32 shape tests of F32_STACK over EVERY shape, in index order.  What a
+    // walk whose box tests are conservative against the shapes' own tests must find: the minimum t (any_hit: the OR).
+    if (mode < 0 || mode > 3) { g_err = "bad mode"; return -1; }
+    if (any_hit && mode != F32_STACK && mode != 3) { g_err = "any_hit is an F32_STACK probe"; return -1; }
     nthreads = std::max(1, nthreads);
     std::vector<std::thread> th;
     for (int w = 0; w < nthreads; ++w)
@@ -1347,7 +1349,22 @@ int orc_trace_rays(const orc_scene* s, int mode, const double* rays, int64_t n, 
                 const double* q = rays + i * 8;
                 TraceCounters tc;
                 int prim = -1; double t = 0;
-                if (mode == F32_STACK) {
+                if (mode == 3) {
+                    const Ray<float> r{{(float)q[0], (float)q[1], (float)q[2]}, {(float)q[3], (float)q[4], (float)q[5]}};
+                    const float tmin = (float)q[6];
+                    Hit<float> best{any_hit ? (float)q[7] : FLT_MAX, {}, {}, -1};
+                    bool got = false;
+                    for (int shape = 0; shape < (int)s->sc.t32.shapes.size() && !(any_hit && got); ++shape) {
+                        tc.leaf++;
+                        const Hit<float> sh = (any_hit && s->sc.t32.shapes[(size_t)shape].kind == RT_SHAPE_TRIANGLE)
+                                                  ? triangle_occludes_f32(s->sc.t32.shapes[(size_t)shape], shape, r, tmin, best.t)
+                                                  : shape_hit(s->sc.t32, shape, r, tmin, best.t);
+                        if (any_hit) { if (sh.t > 0.0f && sh.t <= best.t) got = true; }
+                        else if (sh.t > 0.0f && sh.t < best.t) { best = sh; got = true; }
+                    }
+                    prim = any_hit ? (got ? 1 : 0) : (got ? best.shape : -1);
+                    t = best.t;
+                } else if (mode == F32_STACK) {
                     const Ray<float> r{{(float)q[0], (float)q[1], (float)q[2]}, {(float)q[3], (float)q[4], (float)q[5]}};
                     Hit<float> h;
                     const bool got = trace_stack_f32(s->sc, r, (float)q[6], any_hit ? (float)q[7] : FLT_MAX, any_hit != 0, h, &tc);

@@ -327,3 +327,38 @@ def test_answers_do_not_depend_on_the_tree():
     spec.loader.exec_module(mod)
     bad = [seed for seed in (2, 3, 7, 10, 15, 22, 27, 10002, 10003, 10006, 10050, 10095, 20003, 20010, 20018) if not mod.check_trees(seed)]
     assert not bad, bad
+
+
+@pytest.mark.parametrize("seed", [3, 10002, 10050, 20018, 20003])
+def test_device_walks_find_what_all_shapes_give(backend, bridge, seed):
+    """The device's two walks (nearest hit over the 32-byte records, any hit over the quantised blocks with slabs and shared shape
+    loop) against the oracle's float32 shape tests over EVERY shape, no tree (F32_ALL_SHAPES), on stress scenes 5,000 to 10^5
+    units from the origin: every t and every occlusion answer equal, bit for bit."""
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("stress_slabs", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "stress_slabs.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    spec, scene, kind, scale, off = mod.make_scene(seed)
+    rng = np.random.default_rng(seed)
+    n_rays = 8000
+    px = np.stack([rng.integers(0, spec.Width, n_rays), rng.integers(0, spec.Height, n_rays), rng.integers(0, spec.AntiAliasingFactor, n_rays)], 1).astype(np.int32)
+    with backend.DeviceScene(scene) as dev, bridge.OracleScene(scene) as osc:
+        rays = np.zeros((n_rays, 8), np.float32)
+        rays[:, :6] = dev.camera_rays(spec, px)
+        rays[:, 7] = 3.0e38
+        ids, t = dev.trace_rays(rays)
+        ids_all, t_all = osc.trace_rays(rays.astype(np.float64), mode=bridge.F32_ALL_SHAPES)
+        hit = ids >= 0
+        assert hit.sum() > n_rays // 4 and np.array_equal(hit, ids_all >= 0) and np.array_equal(t[hit], t_all[hit].astype(np.float32))
+        p = (rays[hit, :3] + t[hit, None] * rays[hit, 3:6]).astype(np.float32)
+        lights = [l for l in scene.Lights if hasattr(l, "Position")]
+        L = np.array([[l.Position.X, l.Position.Y, l.Position.Z] for l in lights], np.float32)[rng.integers(0, len(lights), p.shape[0])]
+        j = rng.normal(size=p.shape); j *= (rng.uniform(0, 1, (p.shape[0], 1)) ** (1 / 3)) / np.linalg.norm(j, axis=1, keepdims=True)
+        d = ((L + np.float32(0.25) * j.astype(np.float32)).astype(np.float32) - p).astype(np.float32)
+        dist = np.sqrt((d * d).sum(1, dtype=np.float32)).astype(np.float32)
+        ok = dist > 0
+        sh = np.zeros((int(ok.sum()), 8), np.float32)
+        sh[:, :3], sh[:, 3:6], sh[:, 6], sh[:, 7] = p[ok], d[ok] * (np.float32(1) / dist[ok])[:, None], 0.01, dist[ok]
+        occ, _ = dev.trace_rays(sh, any_hit=True, uniform_tmin=True)
+        occ_all, _ = osc.trace_rays(sh.astype(np.float64), mode=bridge.F32_ALL_SHAPES, any_hit=True)
+        assert 0 < occ.sum() and np.array_equal(occ, occ_all), int((occ != occ_all).sum())
