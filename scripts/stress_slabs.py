@@ -3,7 +3,7 @@ on and with RTGO_SLAB=0 RTGO_BEAM=0 (every shadow ray walked, every shape of eve
 buffers must be bit-identical.  Run on the GPU box: python scripts/stress_slabs.py [scenes [first seed]]
 (seeds from 10000 on: flat axis-aligned sheets, degenerate and duplicate triangles, needles and scene-sized triangles in
 a fine mesh, folded sheets; from 20000 on: lights inside their own jitter's reach of a surface, on a vertex, on the floor,
-eight lights with cones of 1 to 179 degrees, a sphere around everything, a light 300 scene sizes away, a scene without height, a camera 20 scene sizes away)"""
+eight lights with cones of 1 to 179 degrees, a sphere around everything, a light 300 scene sizes away, a scene without height, a camera 20 scene sizes away, 1,500 spheres instead of the mesh)"""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -95,7 +95,7 @@ def make_scene(seed):
         shapes.append(api.TrianglePlane(V(-R, 0, R), V(-R, 8, R), V(R, 0, R), True, api.Metal(api.Vec(0.9, 0.9, 0.9), 0.0)))
     far_camera = False
     if seed >= 20000:  # lights and extents at their limits (seeds from 20000 on; the mesh is the one of seed % 5)
-        var = (seed // 4) % 7
+        var = (seed // 4) % 8
         kind = 10 + var
         if var == 0:    # a light closer to the surface than its own jitter: the hit point is inside the ball of light positions
             k = int(rng.integers(len(tri)))
@@ -117,6 +117,11 @@ def make_scene(seed):
         elif var == 4:  # a light far outside, 300 scene sizes away (beams as long as the coordinates allow)
             lights.append(api.PointLight(ColorFrac=api.Vec(1, 1, 1), Position=V(900.0, 1500.0, -1200.0), LightIntensity=4e6 * scale * scale, SpecularLightIntensity=5,
                                          InverseSquareLawDecayFactor=0.5))
+        elif var == 7:  # spheres instead of the mesh: 1,500 of them, 0.01 to 0.3 units, many overlapping (leaves without a slab, mixed leaves)
+            c = rng.uniform(-3, 3, (1500, 3)) * np.array([1.0, 0.35, 1.0]) + np.array([0.0, 1.6, 0.0])
+            r = 0.01 + 0.29 * rng.uniform(0, 1, 1500) ** 3
+            shapes = shapes[:2] + [api.Sphere(V(c[q, 0], c[q, 1], c[q, 2]), float(r[q]) * scale, mat) for q in range(1500)] + \
+                     [api.TrianglePlane(V(-1 + 0.1 * q, 0.5, -1), V(-1 + 0.1 * q, 2.5, 1), V(-0.9 + 0.1 * q, 0.5, 1), False, mat) for q in range(20)]
         elif var == 6:  # the camera 20 scene sizes away behind a long lens: primary rays start far outside the shapes' box
             far_camera = True
             # (no spheres: Sphere.hit's b^2 - a c, kept in the reference's form, cancels in float32 when |o - centre|^2 nears 2^24
