@@ -362,3 +362,42 @@ def test_device_walks_find_what_all_shapes_give(backend, bridge, seed):
         occ, _ = dev.trace_rays(sh, any_hit=True, uniform_tmin=True)
         occ_all, _ = osc.trace_rays(sh.astype(np.float64), mode=bridge.F32_ALL_SHAPES, any_hit=True)
         assert 0 < occ.sum() and np.array_equal(occ, occ_all), int((occ != occ_all).sum())
+
+
+@pytest.mark.parametrize("seed,n_lights", [(0, 17), (1, 40), (5, 130)])
+def test_many_positional_lights(backend, bridge, rt, seed, n_lights):
+    """17, 40 and 130 point and spot lights on top of a stress scene's three (the (hit, light) pair word gives the light 5 to 8 bits,
+    the voxel beams are dropped once their cells would take more than 32 MiB, a round of k_phong_pairs takes four lights):
+    ray counters equal to the oracle's float32 mirror, accumulation buffer within its usual bound, and the frame with
+    slabs and beams bit-identical to the frame without."""
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("stress_slabs", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "stress_slabs.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    spec, scene, kind, scale, off = mod.make_scene(seed)
+    rng = np.random.default_rng(seed)
+    V = lambda x, y, z: rt.Vec(float(x * scale + off[0]), float(y * scale + off[1]), float(z * scale + off[2]))
+    for q in range(n_lights):
+        p = rng.uniform(-5, 5, 3)
+        if q % 2:
+            scene.Lights.append(rt.PointLight(ColorFrac=rt.Vec(1, 1, 1), Position=V(p[0], 3 + abs(p[1]), p[2]), LightIntensity=3 * scale * scale, SpecularLightIntensity=1,
+                                              InverseSquareLawDecayFactor=0.5))
+        else:
+            scene.Lights.append(rt.SpotLight(ColorFrac=rt.Vec(1, 1, 1), Position=V(p[0], 3 + abs(p[1]), p[2]), LightIntensity=3 * scale * scale, SpecularLightIntensity=1,
+                                             LookAt=V(0, 1, 0), Angle=30.0, InverseSquareLawDecayFactor=0.5))
+    spec = rt.ImageSpec(64, 40, 2, 2, 4, 16, rt.Dijkstra)
+    with backend.DeviceScene(scene) as dev, bridge.OracleScene(scene) as osc:
+        os.environ["RTGO_BEAM"] = "1"
+        try:
+            acc, st = dev.render_accum(spec)
+            os.environ["RTGO_SLAB"] = "0"; os.environ["RTGO_BEAM"] = "0"
+            plain, st0 = dev.render_accum(spec)
+        finally:
+            for k in ("RTGO_SLAB", "RTGO_BEAM"):
+                os.environ.pop(k, None)
+        ref, _, ctr = osc.render(spec, mode=bridge.F32_STACK, rgba=False)
+    assert np.array_equal(acc, plain) and st.rays_shadow == st0.rays_shadow
+    assert st.rays_primary == ctr["rays_primary"] and st.rays_continuation == ctr["rays_continuation"]
+    assert st.rays_shadow == ctr["rays_shadow"] and st.phong_hits == ctr["phong_hits"]
+    d = np.abs(acc.astype(np.float64) - ref).max(-1)
+    assert (d > 1e-3).mean() <= 2e-3, f"{(d > 1e-3).sum()} pixels off, max {d.max()}"
